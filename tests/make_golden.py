@@ -1,0 +1,392 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Run in the build container only (needs /root/reference; it never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 TQDM_DISABLE=1 python tests/make_golden.py
+
+What is imported from the reference: `models` (UNetGenerator, NLayerDiscriminator,
+models.py:149-247) as-is, and `train_gan` (train_gan_one_epoch, train_gan.py:46-75)
+with empty `torchvision` stubs in sys.modules and os.makedirs silenced during the
+import (train_gan.py:10 imports torchvision, absent here; train_gan.py:38-39
+creates a hard-coded /Users/mac tree at import time) - SURVEY.md section 8(c).
+
+Only inputs-by-recipe and expected outputs are written: weights and inputs are
+regenerated on both sides by oracle/fill.py from (name, seed); fixtures hold the
+reference's outputs (full arrays when small, strided samples + float64 digests
+when large).  No reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+os.environ.setdefault("TQDM_DISABLE", "1")
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from oracle import fill, nets  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import models  # noqa
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    real_makedirs = os.makedirs
+    os.makedirs = lambda *a, **k: None
+    try:
+        import train_gan  # noqa
+    finally:
+        os.makedirs = real_makedirs
+    return models, train_gan
+
+
+def digest(a, nsample=512):
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    stride = max(1, flat.size // nsample)
+    a64 = flat.astype(np.float64)
+    return dict(sum=a64.sum(), abs_sum=np.abs(a64).sum(), sq_sum=(a64 * a64).sum(),
+                sample=flat[::stride][:nsample].copy(), stride=np.int64(stride), size=np.int64(flat.size))
+
+
+def put_digest(store, name, a):
+    for k, v in digest(a).items():
+        store[f"{name}.{k}"] = v
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+compact = fill.compact
+
+
+def load_state(module, st):
+    module.load_state_dict({k: t(v) for k, v in st.items()}, strict=True)
+
+
+# --------------------------------------------------------------------------- ops
+CONV_CASES = [  # name, N, Ci, H, W, Co, stride, bias
+    ("conv_s2_c3", 2, 3, 16, 16, 8, 2, False),
+    ("conv_s2_c8", 2, 8, 8, 8, 16, 2, False),
+    ("conv_s2_c6b", 1, 6, 12, 12, 8, 2, True),
+    ("conv_s2_1x1", 2, 16, 2, 2, 16, 2, False),
+    ("conv_s1_c8", 2, 8, 9, 9, 16, 1, False),
+    ("conv_s1_co1", 2, 16, 5, 7, 1, 1, True),
+]
+CONVT_CASES = [  # name, N, Ci, H, W, Co, bias
+    ("convT_1x1", 2, 16, 1, 1, 16, False),
+    ("convT_c16", 2, 16, 4, 4, 8, False),
+    ("convT_co3b", 2, 16, 8, 8, 3, True),
+    ("convT_rect", 1, 8, 3, 5, 8, False),
+]
+
+
+def gen_ops():
+    s = {}
+    for name, n, ci, h, w, co, stride, bias in CONV_CASES:
+        m = nn.Conv2d(ci, co, 4, stride, 1, bias=bias)
+        wv = fill.uniform(name + ".w", (co, ci, 4, 4), -0.25, 0.25)
+        bv = fill.uniform(name + ".b", (co,), -0.5, 0.5) if bias else None
+        x = fill.uniform(name + ".x", (n, ci, h, w))
+        with torch.no_grad():
+            m.weight.copy_(t(wv))
+            if bias:
+                m.bias.copy_(t(bv))
+        xt = t(x).requires_grad_(True)
+        y = m(xt)
+        dy = fill.uniform(name + ".dy", tuple(y.shape))
+        y.backward(t(dy))
+        s[name + ".y"] = y.detach().numpy()
+        s[name + ".dx"] = xt.grad.numpy()
+        s[name + ".dw"] = m.weight.grad.numpy()
+        if bias:
+            s[name + ".db"] = m.bias.grad.numpy()
+    for name, n, ci, h, w, co, bias in CONVT_CASES:
+        m = nn.ConvTranspose2d(ci, co, 4, 2, 1, bias=bias)
+        wv = fill.uniform(name + ".w", (ci, co, 4, 4), -0.25, 0.25)
+        bv = fill.uniform(name + ".b", (co,), -0.5, 0.5) if bias else None
+        x = fill.uniform(name + ".x", (n, ci, h, w))
+        with torch.no_grad():
+            m.weight.copy_(t(wv))
+            if bias:
+                m.bias.copy_(t(bv))
+        xt = t(x).requires_grad_(True)
+        y = m(xt)
+        dy = fill.uniform(name + ".dy", tuple(y.shape))
+        y.backward(t(dy))
+        s[name + ".y"] = y.detach().numpy()
+        s[name + ".dx"] = xt.grad.numpy()
+        s[name + ".dw"] = m.weight.grad.numpy()
+        if bias:
+            s[name + ".db"] = m.bias.grad.numpy()
+    # BatchNorm2d, train (two forwards) then eval
+    bn = nn.BatchNorm2d(8)
+    g = fill.uniform("bn.g", (8,), 0.5, 1.5)
+    b = fill.uniform("bn.b", (8,), -0.5, 0.5)
+    x = fill.uniform("bn.x", (4, 8, 5, 5), -2, 3)
+    with torch.no_grad():
+        bn.weight.copy_(t(g))
+        bn.bias.copy_(t(b))
+    xt = t(x).requires_grad_(True)
+    y = bn(xt)
+    dy = fill.uniform("bn.dy", (4, 8, 5, 5))
+    y.backward(t(dy))
+    s["bn.y"] = y.detach().numpy()
+    s["bn.dx"] = xt.grad.numpy()
+    s["bn.dg"] = bn.weight.grad.numpy()
+    s["bn.db"] = bn.bias.grad.numpy()
+    s["bn.rm1"] = bn.running_mean.numpy().copy()
+    s["bn.rv1"] = bn.running_var.numpy().copy()
+    bn(t(x))
+    s["bn.rm2"] = bn.running_mean.numpy().copy()
+    s["bn.rv2"] = bn.running_var.numpy().copy()
+    s["bn.nbt2"] = bn.num_batches_tracked.numpy().copy()
+    bn.eval()
+    s["bn.y_eval"] = bn(t(x)).detach().numpy()
+    # activations
+    x = fill.uniform("act.x", (2, 4, 3, 3), -2, 2)
+    dy = fill.uniform("act.dy", (2, 4, 3, 3))
+    for nm, mod in (("lrelu", nn.LeakyReLU(0.2)), ("relu", nn.ReLU()), ("tanh", nn.Tanh())):
+        xt = t(x).requires_grad_(True)
+        y = mod(xt)
+        y.backward(t(dy))
+        s[f"act.{nm}.y"] = y.detach().numpy()
+        s[f"act.{nm}.dx"] = xt.grad.numpy()
+    # losses (train_gan.py:42-43)
+    x = fill.uniform("bce.x", (2, 1, 6, 6), -4, 4)
+    for tgt in (1.0, 0.0):
+        xt = t(x).requires_grad_(True)
+        loss = nn.BCEWithLogitsLoss()(xt, torch.full_like(xt, tgt))
+        loss.backward()
+        s[f"bce.t{int(tgt)}.loss"] = loss.detach().numpy()
+        s[f"bce.t{int(tgt)}.dx"] = xt.grad.numpy()
+    a = fill.uniform("l1.a", (2, 3, 8, 8))
+    b = fill.uniform("l1.b", (2, 3, 8, 8))
+    at = t(a).requires_grad_(True)
+    loss = nn.L1Loss()(at, t(b))
+    loss.backward()
+    s["l1.loss"] = loss.detach().numpy()
+    s["l1.da"] = at.grad.numpy()
+    # Adam (train_gan.py:140-141), 3 steps on one tensor
+    p = torch.nn.Parameter(t(fill.uniform("adam.p", (64,))))
+    opt = torch.optim.Adam([p], lr=1e-4, betas=(0.5, 0.999))
+    for i in range(3):
+        p.grad = t(fill.uniform(f"adam.g{i}", (64,), -1e-2, 1e-2))
+        opt.step()
+        s[f"adam.p{i + 1}"] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **s)
+    print("ops.npz", len(s), "arrays")
+
+
+# -------------------------------------------------------------------------- nets
+NET_CASES = [  # name, num_downs, ngf, ndf, N, H
+    ("small", 5, 8, 8, 2, 32),
+    ("mid", 6, 16, 16, 3, 64),
+]
+
+
+def _agree(a, b, tol=2e-4):
+    """True when two {name: array} results agree to `tol` of each array's max magnitude."""
+    for k in a:
+        scale = max(np.abs(b[k]).max(), 1e-6)
+        if np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() > tol * scale:
+            return False
+    return True
+
+
+def _pick_seed(run, what):
+    """Smallest data seed whose fp32 reference results agree with the fp64 reference.
+
+    A pre-activation within round-off of 0 flips ReLU'/LeakyReLU' between two equally
+    valid fp32 evaluations (1-3 % on a BN-gamma gradient in the first seed tried); such a
+    knife-edge input pins nothing, so the fixture uses a seed without one.
+    """
+    for seed in range(32):
+        r32 = run(torch.float32, seed)
+        if _agree(r32, run(torch.float64, seed)):
+            print(f"  {what}: data seed {seed}")
+            return seed, r32
+    raise RuntimeError(f"no well-conditioned seed for {what}")
+
+
+def _to(st, dtype):
+    return {k: (t(v).to(dtype) if v.dtype != np.int64 else t(v)) for k, v in st.items()}
+
+
+def gen_nets(models):
+    s = {}
+    for name, nd, ngf, ndf, n, h in NET_CASES:
+        gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=1)
+        dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=2)
+
+        def run_g(dtype, seed):
+            G = models.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).to(dtype)
+            assert list(G.state_dict().keys()) == list(gst.keys()), "generator key order differs from oracle manifest"
+            G.load_state_dict(_to(gst, dtype))
+            x = fill.uniform(f"{name}.x", (n, 3, h, h), seed=seed)
+            G.train()
+            y = G(t(x).to(dtype))
+            dy = fill.uniform(f"{name}.g.dy", tuple(y.shape), seed=seed)
+            y.backward(t(dy).to(dtype))
+            r = {"g.y": y.detach().numpy()}
+            for k, p in G.named_parameters():
+                r[f"g.grad.{k}"] = p.grad.numpy()
+            for k, b in G.named_buffers():
+                r[f"g.buf.{k}"] = b.numpy().copy()
+            G.eval()
+            with torch.no_grad():
+                r["g.y_eval"] = G(t(x).to(dtype)).numpy()
+            return r
+
+        def run_d(dtype, seed):
+            D = models.NLayerDiscriminator(6, ndf=ndf).to(dtype)
+            assert list(D.state_dict().keys()) == list(dst.keys()), "discriminator key order differs"
+            D.load_state_dict(_to(dst, dtype))
+            xd = fill.uniform(f"{name}.xd", (n, 6, h, h), seed=seed)
+            D.train()
+            xdt = t(xd).to(dtype).requires_grad_(True)
+            y = D(xdt)
+            dy = fill.uniform(f"{name}.d.dy", tuple(y.shape), seed=seed)
+            y.backward(t(dy).to(dtype))
+            r = {"d.y": y.detach().numpy(), "d.dx": xdt.grad.numpy()}
+            for k, p in D.named_parameters():
+                r[f"d.grad.{k}"] = p.grad.numpy()
+            for k, b in D.named_buffers():
+                r[f"d.buf.{k}"] = b.numpy().copy()
+            D.eval()
+            with torch.no_grad():
+                r["d.y_eval"] = D(xdt.detach()).numpy()
+            return r
+
+        for tag, run in (("g", run_g), ("d", run_d)):
+            seed, r = _pick_seed(run, f"nets.{name}.{tag}")
+            s[f"{name}.{tag}.seed"] = np.int64(seed)
+            for k, v in r.items():
+                s[f"{name}.{k}"] = compact(v) if ".grad." in k else v
+    np.savez_compressed(os.path.join(OUT, "nets.npz"), **s)
+    print("nets.npz", len(s), "arrays")
+
+
+def gen_full(models):
+    """Default-size networks (num_downs=7, ngf=64 / ndf=64): digests only."""
+    s = {}
+    torch.set_num_threads(8)
+    G = models.UNetGenerator(3, 3)
+    gshapes = nets.g_state_shapes()
+    gst = fill.fill_state(gshapes, seed=3)
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == {k: tuple(v) for k, v in gshapes.items()}
+    load_state(G, gst)
+    D = models.NLayerDiscriminator(6)
+    dshapes = nets.d_state_shapes()
+    dst = fill.fill_state(dshapes, seed=4)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == {k: tuple(v) for k, v in dshapes.items()}
+    load_state(D, dst)
+    for tag, n, h in (("b2_128", 2, 128), ("b1_256", 1, 256)):
+        x = fill.uniform(f"full.{tag}.x", (n, 3, h, h))
+        G.train()
+        with torch.no_grad():
+            y = G(t(x)).numpy()
+        put_digest(s, f"full.{tag}.g.y", y)
+        s[f"full.{tag}.g.y_chan_mean"] = y.astype(np.float64).mean(axis=(0, 2, 3))
+        G.eval()
+        # reload so the eval forward sees pristine buffers (the train forward updated them)
+        bufs = {k: b.numpy().copy() for k, b in G.named_buffers() if "running" in k}
+        put_digest(s, f"full.{tag}.g.running_cat", np.concatenate([v.reshape(-1) for v in bufs.values()]))
+        load_state(G, gst)
+        with torch.no_grad():
+            ye = G(t(x)).numpy()
+        put_digest(s, f"full.{tag}.g.y_eval", ye)
+        xd = fill.uniform(f"full.{tag}.xd", (n, 6, h, h))
+        D.train()
+        with torch.no_grad():
+            yd = D(t(xd)).numpy()
+        s[f"full.{tag}.d.y"] = yd
+        load_state(D, dst)
+    np.savez_compressed(os.path.join(OUT, "full.npz"), **s)
+    print("full.npz", len(s), "arrays")
+
+
+# -------------------------------------------------------------------------- step
+STEP_CASES = [  # name, num_downs, ngf, ndf, N, H, steps
+    ("small", 5, 8, 8, 2, 32, 2),
+    ("mid", 6, 16, 16, 2, 64, 2),
+]
+
+
+def gen_step(models, train_gan):
+    s = {}
+    for name, nd, ngf, ndf, n, h, steps in STEP_CASES:
+        gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False)
+        dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False)
+
+        def run(dtype, seed):
+            G = models.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).to(dtype)
+            D = models.NLayerDiscriminator(6, ndf=ndf).to(dtype)
+            G.load_state_dict(_to(gst, dtype))
+            D.load_state_dict(_to(dst, dtype))
+            og = torch.optim.Adam(G.parameters(), lr=train_gan.LEARNING_RATE_G, betas=(train_gan.BETA1, 0.999))
+            od = torch.optim.Adam(D.parameters(), lr=train_gan.LEARNING_RATE_D, betas=(train_gan.BETA1, 0.999))
+            r = {}
+            captured = {}
+            od.register_step_pre_hook(
+                lambda *a: captured.__setitem__("d", {k: p.grad.numpy().copy() for k, p in D.named_parameters()}))
+            og.register_step_pre_hook(
+                lambda *a: captured.__setitem__("g", {k: p.grad.numpy().copy() for k, p in G.named_parameters()}))
+            for i in range(steps):
+                batch = dict(image1=t(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).to(dtype),
+                             image2=t(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).to(dtype))
+                ld, lg = train_gan.train_gan_one_epoch(G, D, [batch], og, od)
+                r[f"loss_d{i}"] = np.float32(ld)
+                r[f"loss_g{i}"] = np.float32(lg)
+                for k, v in captured["d"].items():
+                    r[f"dgrad{i}.{k}"] = compact(v)
+                for k, v in captured["g"].items():
+                    r[f"ggrad{i}.{k}"] = compact(v)
+            for k, v in G.state_dict().items():
+                r[f"g.{k}"] = compact(v.numpy())
+            for k, v in D.state_dict().items():
+                r[f"d.{k}"] = compact(v.numpy())
+            return r
+
+        def run_grads_only(dtype, seed):
+            return {k: v for k, v in run(dtype, seed).items() if "grad" in k or "loss" in k}
+
+        seed, _ = _pick_seed(run_grads_only, f"step.{name}")
+        s[f"step.{name}.seed"] = np.int64(seed)
+        for k, v in run(torch.float32, seed).items():
+            s[f"step.{name}.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "step.npz"), **s)
+    print("step.npz", len(s), "arrays")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    models, train_gan = import_reference()
+    gen_ops()
+    gen_nets(models)
+    gen_full(models)
+    gen_step(models, train_gan)
+    with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
+        f.write("generated by tests/make_golden.py from /root/reference (Affi-Amine/GAN-AUG-PFA @ 2025-06-14)\n")
+        f.write(f"torch {torch.__version__} CPU, numpy {np.__version__}\n")
+        for fn in sorted(os.listdir(OUT)):
+            if fn.endswith(".npz"):
+                f.write(f"{fn} {os.path.getsize(os.path.join(OUT, fn))} bytes\n")
+
+
+if __name__ == "__main__":
+    main()
