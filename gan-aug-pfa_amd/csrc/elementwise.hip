@@ -1,0 +1,605 @@
+// HBM-bound kernels of the GAN step: BatchNorm statistics / apply / backward, activations, losses,
+// Adam, weight shadows and layout conversion.  All tensors are NHWC viewed as [rows][c], moved in
+// 16-byte chunks per lane (coalesced: consecutive lanes touch consecutive chunks).
+//
+// Reference semantics restated here (file:line in /root/reference):
+//   nn.BatchNorm2d training/eval        models.py:179,181,231,239 (eps 1e-5, momentum 0.1)
+//   nn.LeakyReLU(0.2) / nn.ReLU / Tanh  models.py:178,180,186,223,232,240
+//   BCEWithLogitsLoss / L1Loss          train_gan.py:42-43,58-61,67-69
+//   optim.Adam(lr, betas=(0.5,0.999))   train_gan.py:140-141
+#include "pfa_common.h"
+
+thread_local char g_pfa_err[512] = "";
+std::atomic<uint64_t> g_pfa_launches{0};
+
+extern "C" int pfa_version(void) { return 100; }
+extern "C" const char* pfa_last_error_string(void) { return g_pfa_err; }
+extern "C" uint64_t pfa_launch_count(void) { return g_pfa_launches.load(); }
+
+namespace {
+
+inline int grid_for(int64_t work, int block = 256, int cap = 256 * 16) {
+    int64_t g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics
+__global__ void k_bn_finalize(const float* __restrict__ psum, const float* __restrict__ psq, int ntiles, int c,
+                              double count, const float* gamma, const float* beta, float eps, float momentum,
+                              int repeats, float* running_mean, float* running_var, int64_t* nbt, float* scale,
+                              float* shift, float* mean_out, float* invstd_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) *nbt += repeats;
+    if (ch >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        s += (double)psum[(size_t)t * c + ch];
+        q += (double)psq[(size_t)t * c + ch];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
+    scale[ch] = (float)(g * invstd);
+    shift[ch] = (float)(b - mean * g * invstd);
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    if (running_mean && repeats > 0) {
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        double rm = running_mean[ch], rv = running_var[ch];
+        for (int r = 0; r < repeats; ++r) {
+            rm = (1.0 - momentum) * rm + momentum * mean;
+            rv = (1.0 - momentum) * rv + momentum * unb;
+        }
+        running_mean[ch] = (float)rm;
+        running_var[ch] = (float)rv;
+    }
+}
+
+__global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 int c, float* scale, float* shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    const double invstd = 1.0 / sqrt((double)rv[ch] + (double)eps);
+    const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
+    scale[ch] = (float)(g * invstd);
+    shift[ch] = (float)(b - (double)rm[ch] * g * invstd);
+}
+
+// ------------------------------------------------------------------ normalise + dual activation
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act(const T* __restrict__ raw, int64_t nchunks, int cpr,
+                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                float slope, T* out_l, T* out_r) {
+    constexpr int CH = ElemTraits<T>::CH;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(idx % cpr) * CH;
+        Chunk<T> x, l, r;
+        x.load(raw + idx * CH);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float y = scale ? x.v[e] * scale[c0 + e] + shift[c0 + e] : x.v[e];
+            l.v[e] = y >= 0.f ? y : y * slope;
+            r.v[e] = y > 0.f ? y : 0.f;
+        }
+        if (out_l) l.store(out_l + idx * CH);
+        if (out_r) r.store(out_r + idx * CH);
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm backward, pass 1
+// dy = act1'(y) g1 + act2'(y) g2 ; partial sums of dy and dy*xhat per channel and block.
+constexpr int BWD_PASSES = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw, int64_t rows, int c, int cpr,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const T* __restrict__ g1,
+                                                       int act1, const T* __restrict__ g2, int act2, float slope,
+                                                       T* dy, float* part, int ntiles) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ float red[2][256][CH];
+    const int tid = threadIdx.x;
+    const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
+    const int c0 = col * CH;
+    float sc[CH], sh[CH], mu[CH], is[CH], s_dy[CH], s_dyx[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        sc[e] = scale ? scale[c0 + e] : 1.f;
+        sh[e] = scale ? shift[c0 + e] : 0.f;
+        mu[e] = mean ? mean[c0 + e] : 0.f;
+        is[e] = mean ? invstd[c0 + e] : 1.f;
+        s_dy[e] = 0.f;
+        s_dyx[e] = 0.f;
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * rpp * BWD_PASSES;
+    for (int ps = 0; ps < BWD_PASSES; ++ps) {
+        const int64_t row = row0 + (int64_t)ps * rpp + rsub;
+        if (row >= rows) break;
+        const int64_t off = (row * cpr + col) * CH;
+        Chunk<T> x, a, b, o;
+        x.load(raw + off);
+        a.load(g1 + off);
+        if (g2) b.load(g2 + off);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float y = x.v[e] * sc[e] + sh[e];
+            float d = act_grad(y, act1, slope) * a.v[e];
+            if (g2) d += act_grad(y, act2, slope) * b.v[e];
+            o.v[e] = d;
+            s_dy[e] += d;
+            s_dyx[e] += d * ((x.v[e] - mu[e]) * is[e]);
+        }
+        o.store(dy + off);
+    }
+    if (!part) return;
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { red[0][tid][e] = s_dy[e]; red[1][tid][e] = s_dyx[e]; }
+    __syncthreads();
+    if (tid < cpr) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < rpp; ++r) { a += red[0][r * cpr + tid][e]; b += red[1][r * cpr + tid][e]; }
+            part[(size_t)blockIdx.x * c + tid * CH + e] = a;
+            part[((size_t)ntiles + blockIdx.x) * c + tid * CH + e] = b;
+        }
+    }
+}
+
+__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int ntiles, int c, double count,
+                                  const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                  float* dbeta, float* coef) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double sdy = 0.0, sdyx = 0.0;
+    for (int t = 0; t < ntiles; ++t) {
+        sdy += (double)part[(size_t)t * c + ch];
+        sdyx += (double)part[((size_t)ntiles + t) * c + ch];
+    }
+    if (dgamma) dgamma[ch] += (float)sdyx;       // gradients accumulate into a zeroed arena (zero_grad semantics)
+    if (dbeta) dbeta[ch] += (float)sdy;
+    const double g = gamma ? (double)gamma[ch] : 1.0;
+    const double is = invstd[ch], mu = mean[ch];
+    const double s = g * is;
+    // dr = s*(dy - sdy/cnt - xhat*sdyx/cnt),  xhat = (raw-mu)*is
+    coef[ch] = (float)s;
+    coef[c + ch] = (float)(-s * is * sdyx / count);
+    coef[2 * c + ch] = (float)(-s * sdy / count + s * is * mu * sdyx / count);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* dy, const T* __restrict__ raw, int64_t nchunks,
+                                                      int cpr, int c, const float* __restrict__ coef, T* dr) {
+    constexpr int CH = ElemTraits<T>::CH;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(idx % cpr) * CH;
+        Chunk<T> d, x, o;
+        d.load(dy + idx * CH);
+        x.load(raw + idx * CH);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) o.v[e] = coef[c0 + e] * d.v[e] + coef[c + c0 + e] * x.v[e] + coef[2 * c + c0 + e];
+        o.store(dr + idx * CH);
+    }
+}
+
+// ------------------------------------------------------------------ losses
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;   // valid on thread 0
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bce_logits(const T* __restrict__ logits, int64_t count, int ld, float target,
+                                                    float lscale, float gscale, float* loss_acc, T* dlogits) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ float sh[4];
+    float local = 0.f;
+    const int cpr = ld / CH;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float x = to_f32(logits[i * ld]);
+        local += fmaxf(x, 0.f) - x * target + log1pf(expf(-fabsf(x)));
+        if (dlogits) {
+            const float sg = 1.f / (1.f + expf(-x));
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) o.v[e] = 0.f;
+            for (int k = 1; k < cpr; ++k) o.store(dlogits + i * ld + k * CH);
+            o.v[0] = gscale * (sg - target) / (float)count;
+            o.store(dlogits + i * ld);
+        }
+    }
+    const float t = block_sum(local, sh);
+    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, lscale * t / (float)count);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_l1_tanh_bwd(const T* __restrict__ fake, const T* __restrict__ real,
+                                                     int64_t count, int ld, int c_real, const T* __restrict__ dgan,
+                                                     int dgan_ld, int dgan_off, float lambda, float* loss_acc,
+                                                     T* dpre) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ float sh[4];
+    const int cpr = ld / CH;
+    const int64_t nchunks = count * cpr;
+    const float inv = 1.f / ((float)count * (float)c_real);
+    float local = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pix = idx / cpr;
+        const int c0 = (int)(idx - pix * cpr) * CH;
+        Chunk<T> f, r, o;
+        f.load(fake + idx * CH);
+        r.load(real + idx * CH);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            float d = 0.f;
+            if (c0 + e < c_real) {
+                const float df = f.v[e] - r.v[e];
+                local += fabsf(df);
+                const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                d = lambda * sgn * inv;
+                if (dgan) d += to_f32(dgan[pix * dgan_ld + dgan_off + c0 + e]);
+                d *= 1.f - f.v[e] * f.v[e];
+            }
+            o.v[e] = d;
+        }
+        if (dpre) o.store(dpre + idx * CH);
+    }
+    const float t = block_sum(local, sh);
+    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, lambda * t * inv);
+}
+
+// ------------------------------------------------------------------ column sums
+constexpr int COLSUM_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, int64_t rows, int c, float* ws) {
+    // block = COLSUM_ROWS rows; thread t owns columns t, t+256, ...
+    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
+    const int64_t r1 = r0 + COLSUM_ROWS < rows ? r0 + COLSUM_ROWS : rows;
+    for (int col = threadIdx.x; col < c; col += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * c + col]);
+        ws[(size_t)blockIdx.x * c + col] = s;
+    }
+}
+__global__ void k_colsum_final(const float* __restrict__ ws, int nblk, int c, int c_out, float* out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c_out) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * c + col];
+    out[col] += (float)s;
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void k_adam_tick(int32_t* step) { *step += 1; }
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                              float b1, float b2, float eps, int step, const int32_t* step_dev,
+                                              float grad_scale) {
+    const int t = step_dev ? *step_dev : step;
+    // torch: step_size = lr/(1-b1^t); denom = sqrt(v)/sqrt(1-b2^t) + eps
+    const float bc1 = 1.f - powf(b1, (float)t);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)t));
+    const float step_size = lr / bc1;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gg[e] * grad_scale;
+            mm[e] = b1 * mm[e] + (1.f - b1) * ge;
+            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
+            pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) / bc2s + eps));
+        }
+        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float ge = g[i] * grad_scale;
+        const float me = b1 * m[i] + (1.f - b1) * ge;
+        const float ve = b2 * v[i] + (1.f - b2) * ge * ge;
+        m[i] = me; v[i] = ve;
+        p[i] -= step_size * (me / (sqrtf(ve) / bc2s + eps));
+    }
+}
+
+// ------------------------------------------------------------------ weight shadows
+__device__ __forceinline__ int real_channel(int cp, int c1r, int c1p, int c2r) {
+    if (cp < c1p) return cp < c1r ? cp : -1;
+    const int c2 = cp - c1p;
+    return c2 < c2r ? c1r + c2 : -1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_shadow_same(const float* __restrict__ master, int rows, int cr, int c1r,
+                                                     int c1p, int c2r, int cp_tot, T* same) {
+    const int64_t total = (int64_t)rows * 16 * cp_tot;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int cp = (int)(idx % cp_tot);
+        const int64_t rt = idx / cp_tot;     // row*16 + tap
+        const int c = real_channel(cp, c1r, c1p, c2r);
+        same[idx] = from_f32<T>(c >= 0 ? master[rt * cr + c] : 0.f);
+    }
+}
+
+// tr[cp][tap][r] = master[r][tap][creal(cp)]: 32x32 tiles through LDS, both sides coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void k_shadow_tr(const float* __restrict__ master, int rows, int cr, int c1r,
+                                                   int c1p, int c2r, int cp_tot, int rows_p, T* tr) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int cp0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, cp = cp0 + tx;
+        float v = 0.f;
+        if (r < rows && cp < cp_tot) {
+            const int c = real_channel(cp, c1r, c1p, c2r);
+            if (c >= 0) v = master[((size_t)r * 16 + tap) * cr + c];
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int cp = cp0 + ty + 8 * k, r = r0 + tx;
+        if (cp < cp_tot && r < rows_p) tr[((size_t)cp * 16 + tap) * rows_p + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+    }
+}
+
+// ------------------------------------------------------------------ NCHW float32 <-> NHWC T
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_nhwc(const float* __restrict__ src, int n, int c, int64_t hw, int cp,
+                                                   T* dst) {
+    const int64_t total = (int64_t)n * hw;
+    for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
+        const int64_t img = pix / hw, off = pix - img * hw;
+        for (int ch = 0; ch < cp; ++ch)
+            dst[pix * cp + ch] = from_f32<T>(ch < c ? src[(img * c + ch) * hw + off] : 0.f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_nchw(const T* __restrict__ src, int n, int c, int64_t hw, int cp,
+                                                     float* dst) {
+    const int64_t total = (int64_t)n * c * hw;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t off = idx % hw, t = idx / hw;
+        const int ch = (int)(t % c);
+        const int64_t img = t / c;
+        dst[idx] = to_f32(src[(img * hw + off) * cp + ch]);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, expr_bf16, expr_f32)           \
+    do {                                                 \
+        if ((dtype) == PFA_BF16) { expr_bf16; }          \
+        else if ((dtype) == PFA_F32) { expr_f32; }       \
+        else PFA_FAIL(-1, "bad dtype %d", (int)(dtype)); \
+    } while (0)
+
+extern "C" int pfa_bn_finalize(const float* psum, const float* psq, int ntiles, int c, double count,
+                               const float* gamma, const float* beta, float eps, float momentum, int repeats,
+                               float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
+                               float* mean, float* invstd, pfa_stream s) {
+    PFA_REQUIRE(psum && psq && scale && shift && ntiles > 0 && c > 0 && count > 0, "pfa_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)s, psum, psq, ntiles, c, count,
+                       gamma, beta, eps, momentum, repeats, running_mean, running_var, nbt, scale, shift, mean, invstd);
+    PFA_LAUNCHED("k_bn_finalize");
+    return 0;
+}
+
+extern "C" int pfa_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                  int c, float* scale, float* shift, pfa_stream s) {
+    PFA_REQUIRE(rm && rv && scale && shift && c > 0, "pfa_bn_eval_coeffs: bad arguments");
+    hipLaunchKernelGGL(k_bn_eval_coeffs, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)s, gamma, beta, rm, rv, eps, c,
+                       scale, shift);
+    PFA_LAUNCHED("k_bn_eval_coeffs");
+    return 0;
+}
+
+extern "C" int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const float* scale, const float* shift,
+                          float slope, void* out_l, void* out_r, pfa_stream s) {
+    PFA_REQUIRE(raw && rows > 0 && c > 0 && (out_l || out_r), "pfa_bn_act: bad arguments");
+    PFA_REQUIRE(c % pfa_ch(dtype) == 0, "pfa_bn_act: c=%d not a multiple of %d", c, pfa_ch(dtype));
+    const int cpr = c / pfa_ch(dtype);
+    const int64_t nchunks = rows * cpr;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bn_act<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)raw, nchunks, cpr, scale, shift, slope, (bf16_t*)out_l, (bf16_t*)out_r),
+               hipLaunchKernelGGL(k_bn_act<float>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+                                  (const float*)raw, nchunks, cpr, scale, shift, slope, (float*)out_l, (float*)out_r));
+    PFA_LAUNCHED("k_bn_act");
+    return 0;
+}
+
+extern "C" int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, const void* g1, int act1,
+                                 const void* g2, int act2, float slope, void* dy, float* part, int* ntiles,
+                                 pfa_stream s) {
+    PFA_REQUIRE(raw && g1 && dy && rows > 0 && c > 0, "pfa_bn_bwd_reduce: bad arguments");
+    const int ch = pfa_ch(dtype);
+    PFA_REQUIRE(c % ch == 0, "pfa_bn_bwd_reduce: c=%d not a multiple of %d", c, ch);
+    const int cpr = c / ch;
+    PFA_REQUIRE(cpr <= 256 && 256 % cpr == 0, "pfa_bn_bwd_reduce: c/%d = %d must divide 256", ch, cpr);
+    PFA_REQUIRE((mean == nullptr) == (part == nullptr), "pfa_bn_bwd_reduce: mean and part come together");
+    const int rows_per_block = (256 / cpr) * BWD_PASSES;
+    const int tiles = (int)((rows + rows_per_block - 1) / rows_per_block);
+    if (ntiles) *ntiles = tiles;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)raw, rows, c, cpr, scale, shift, mean, invstd, (const bf16_t*)g1, act1,
+                                  (const bf16_t*)g2, act2, slope, (bf16_t*)dy, part, tiles),
+               hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(tiles), dim3(256), 0, (hipStream_t)s, (const float*)raw,
+                                  rows, c, cpr, scale, shift, mean, invstd, (const float*)g1, act1, (const float*)g2,
+                                  act2, slope, (float*)dy, part, tiles));
+    PFA_LAUNCHED("k_bn_bwd_reduce");
+    return 0;
+}
+
+extern "C" int pfa_bn_bwd_tiles(int64_t rows, int c, int dtype) {
+    const int cpr = c / pfa_ch(dtype);
+    if (cpr < 1 || cpr > 256 || 256 % cpr) return -1;
+    const int rows_per_block = (256 / cpr) * BWD_PASSES;
+    return (int)((rows + rows_per_block - 1) / rows_per_block);
+}
+
+extern "C" int pfa_bn_bwd_finalize(const float* part, int ntiles, int c, double count, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
+                                   pfa_stream s) {
+    PFA_REQUIRE(part && mean && invstd && coef && ntiles > 0 && c > 0, "pfa_bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)s, part, ntiles, c, count,
+                       gamma, mean, invstd, dgamma, dbeta, coef);
+    PFA_LAUNCHED("k_bn_bwd_finalize");
+    return 0;
+}
+
+extern "C" int pfa_bn_bwd_apply(const void* dy, const void* raw, int64_t rows, int c, int dtype, const float* coef,
+                                void* dr, pfa_stream s) {
+    PFA_REQUIRE(dy && raw && coef && dr && rows > 0, "pfa_bn_bwd_apply: bad arguments");
+    PFA_REQUIRE(c % pfa_ch(dtype) == 0, "pfa_bn_bwd_apply: c not a multiple of the chunk width");
+    const int cpr = c / pfa_ch(dtype);
+    const int64_t nchunks = rows * cpr;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)dy, (const bf16_t*)raw, nchunks, cpr, c, coef, (bf16_t*)dr),
+               hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+                                  (const float*)dy, (const float*)raw, nchunks, cpr, c, coef, (float*)dr));
+    PFA_LAUNCHED("k_bn_bwd_apply");
+    return 0;
+}
+
+extern "C" int pfa_bce_logits(const void* logits, int64_t count, int ld, int dtype, float target, float lscale,
+                              float gscale, float* loss_acc, void* dlogits, pfa_stream s) {
+    PFA_REQUIRE(logits && count > 0 && ld > 0 && ld % pfa_ch(dtype) == 0, "pfa_bce_logits: bad arguments");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bce_logits<bf16_t>, dim3(grid_for(count, 256, 64)), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)logits, count, ld, target, lscale, gscale, loss_acc, (bf16_t*)dlogits),
+               hipLaunchKernelGGL(k_bce_logits<float>, dim3(grid_for(count, 256, 64)), dim3(256), 0, (hipStream_t)s,
+                                  (const float*)logits, count, ld, target, lscale, gscale, loss_acc, (float*)dlogits));
+    PFA_LAUNCHED("k_bce_logits");
+    return 0;
+}
+
+extern "C" int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                               const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
+                               pfa_stream s) {
+    PFA_REQUIRE(fake && real && count > 0 && ld > 0 && ld % pfa_ch(dtype) == 0 && c_real > 0 && c_real <= ld,
+                "pfa_l1_tanh_bwd: bad arguments");
+    const int64_t nchunks = count * (ld / pfa_ch(dtype));
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_l1_tanh_bwd<bf16_t>, dim3(grid_for(nchunks, 256, 1024)), dim3(256), 0,
+                                  (hipStream_t)s, (const bf16_t*)fake, (const bf16_t*)real, count, ld, c_real,
+                                  (const bf16_t*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (bf16_t*)dpre),
+               hipLaunchKernelGGL(k_l1_tanh_bwd<float>, dim3(grid_for(nchunks, 256, 1024)), dim3(256), 0,
+                                  (hipStream_t)s, (const float*)fake, (const float*)real, count, ld, c_real,
+                                  (const float*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (float*)dpre));
+    PFA_LAUNCHED("k_l1_tanh_bwd");
+    return 0;
+}
+
+extern "C" size_t pfa_colsum_ws(int64_t rows, int c) {
+    return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * (size_t)c;
+}
+
+extern "C" int pfa_colsum(const void* x, int64_t rows, int c, int c_out, int dtype, float* out, float* ws,
+                          pfa_stream s) {
+    PFA_REQUIRE(x && out && ws && rows > 0 && c > 0 && c_out > 0 && c_out <= c, "pfa_colsum: bad arguments");
+    const int nblk = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_colsum_partial<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x,
+                                  rows, c, ws),
+               hipLaunchKernelGGL(k_colsum_partial<float>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const float*)x,
+                                  rows, c, ws));
+    PFA_LAUNCHED("k_colsum_partial");
+    hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 63) / 64), dim3(64), 0, (hipStream_t)s, ws, nblk, c, c_out, out);
+    PFA_LAUNCHED("k_colsum_final");
+    return 0;
+}
+
+extern "C" int pfa_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, int step, const int32_t* step_dev, float grad_scale, pfa_stream s) {
+    PFA_REQUIRE(p && g && m && v && n > 0, "pfa_adam: bad arguments");
+    PFA_REQUIRE(step_dev || step >= 1, "pfa_adam: step must be >= 1");
+    PFA_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "pfa_adam: arenas must be 16-byte aligned");
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr,
+                       beta1, beta2, eps, step, step_dev, grad_scale);
+    PFA_LAUNCHED("k_adam");
+    return 0;
+}
+
+extern "C" int pfa_adam_tick(int32_t* step_dev, pfa_stream s) {
+    PFA_REQUIRE(step_dev, "pfa_adam_tick: null");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)s, step_dev);
+    PFA_LAUNCHED("k_adam_tick");
+    return 0;
+}
+
+extern "C" int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p, int c2r, int c2p, int rows_p,
+                                 int dtype, void* same, void* tr, pfa_stream s) {
+    PFA_REQUIRE(master && rows > 0 && c1r > 0 && c1r <= c1p && c2r <= c2p && rows_p >= rows, "pfa_weight_shadow: bad arguments");
+    const int cr = c1r + c2r, cp = c1p + c2p;
+    if (same) {
+        const int64_t total = (int64_t)rows * 16 * cp;
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(k_shadow_same<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                      master, rows, cr, c1r, c1p, c2r, cp, (bf16_t*)same),
+                   hipLaunchKernelGGL(k_shadow_same<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, master,
+                                      rows, cr, c1r, c1p, c2r, cp, (float*)same));
+        PFA_LAUNCHED("k_shadow_same");
+    }
+    if (tr) {
+        dim3 grid((cp + 31) / 32, (rows_p + 31) / 32, 16);
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL(k_shadow_tr<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, master, rows, cr, c1r,
+                                      c1p, c2r, cp, rows_p, (bf16_t*)tr),
+                   hipLaunchKernelGGL(k_shadow_tr<float>, grid, dim3(256), 0, (hipStream_t)s, master, rows, cr, c1r, c1p,
+                                      c2r, cp, rows_p, (float*)tr));
+        PFA_LAUNCHED("k_shadow_tr");
+    }
+    return 0;
+}
+
+extern "C" int pfa_pack_nhwc(const float* src, int n, int c, int h, int w, int cp, int dtype, void* dst, pfa_stream s) {
+    PFA_REQUIRE(src && dst && n > 0 && c > 0 && cp >= c && h > 0 && w > 0, "pfa_pack_nhwc: bad arguments");
+    const int64_t hw = (int64_t)h * w;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_pack_nhwc<bf16_t>, dim3(grid_for(n * hw)), dim3(256), 0, (hipStream_t)s, src, n, c,
+                                  hw, cp, (bf16_t*)dst),
+               hipLaunchKernelGGL(k_pack_nhwc<float>, dim3(grid_for(n * hw)), dim3(256), 0, (hipStream_t)s, src, n, c, hw,
+                                  cp, (float*)dst));
+    PFA_LAUNCHED("k_pack_nhwc");
+    return 0;
+}
+
+extern "C" int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dtype, float* dst,
+                               pfa_stream s) {
+    PFA_REQUIRE(src && dst && n > 0 && c > 0 && cp >= c && h > 0 && w > 0, "pfa_unpack_nchw: bad arguments");
+    const int64_t hw = (int64_t)h * w;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_unpack_nchw<bf16_t>, dim3(grid_for(n * c * hw)), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)src, n, c, hw, cp, dst),
+               hipLaunchKernelGGL(k_unpack_nchw<float>, dim3(grid_for(n * c * hw)), dim3(256), 0, (hipStream_t)s,
+                                  (const float*)src, n, c, hw, cp, dst));
+    PFA_LAUNCHED("k_unpack_nchw");
+    return 0;
+}
+
+extern "C" int pfa_fill_zero(void* p, size_t bytes, pfa_stream s) {
+    PFA_REQUIRE(p || bytes == 0, "pfa_fill_zero: null");
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)s);
+    if (e != hipSuccess) PFA_FAIL((int)e, "pfa_fill_zero: %s", hipGetErrorString(e));
+    return 0;
+}

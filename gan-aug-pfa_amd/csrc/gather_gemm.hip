@@ -1,0 +1,454 @@
+// Implicit-GEMM gather kernel on MFMA: Conv2d / ConvTranspose2d forward and input gradients.
+//
+// Replaces nn.Conv2d (models.py:177,223,230,238,243) and nn.ConvTranspose2d (models.py:184,189,194)
+// forward, and the input-gradient halves of their autograd backward (train_gan.py:62,70).
+//
+// GEMM view (no im2col buffer): rows m = output positions, columns n = output channels,
+// K = (tap, channel) with the channel contiguous in NHWC memory.  One K-step is 128 bytes per row
+// (64 bf16 / 32 f32 channels) = 8 chunks of 16 B; chunk f of the flattened K axis is
+// (tap = f / chunks_per_tap, channel chunk = f % chunks_per_tap), so layers with few channels
+// (3 -> padded 8) pack several taps into one K-step instead of wasting it.
+//
+// Data path: every lane owns one 16-B chunk slot of the LDS tile and fetches it with
+// global_load_lds_dwordx4 straight from HBM/L2 into LDS (per-lane source address = the gather;
+// out-of-image taps, K tails and missing weight rows point at a zero page).  The LDS image is
+// lane-linear, so the bank-conflict swizzle (chunk ^= (row>>1)&7) is applied to the SOURCE chunk
+// index and again on the ds_read_b128 fragment reads.  Two LDS stages, one barrier per K-step.
+// MFMA orientation is D[n][m] (weights = A operand, activations = B operand): a lane then holds
+// 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
+#include "pfa_common.h"
+
+namespace {
+
+struct GatherK {
+    const char* src1;
+    const char* src2;
+    const char* w;
+    char* out1;
+    char* out2;
+    const float* bias;
+    float* psum;
+    float* psq;
+    float* slab;
+    int mode, nb, hq, wq, hs, ws;
+    int c1, c2, ctot;
+    int cpt, cpt_shift, ktot, ksteps;
+    int n, n1, ld1, ld2;
+    int M, ho, wo, npix;
+    int splitk, kper;
+    int act;
+    float slope;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4 frag;
+    // 16 floats of K per (lane group, chunk): lane group kk supplies k = 4*kk + j to MFMA j for BOTH
+    // operands, so products pair on the same k; the order of the k-sum is permuted, nothing else.
+    static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T> __device__ __forceinline__ void store4(char* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(char* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)p = t;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(char* p, const float* v) {
+    bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4*)p = t;
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
+    constexpr int CH = ElemTraits<T>::CH;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int AROWS = BM / 32;
+    constexpr int WROWS = BN >= 32 ? BN / 32 : 1;
+    static_assert(WM * WN == 4 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WM, wn = wave / WM;
+    const int split = blockIdx.z % p.splitk, cls = blockIdx.z / p.splitk;
+    const int py = cls >> 1, px = cls & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const char* zero = (const char*)g_pfa_zero_page;
+
+    // ---- staging roles: this thread fills chunk slot `cs` of rows r0 + 32*i
+    const int cs = tid & 7, r0 = tid >> 3;
+    const int g = cs ^ ((r0 >> 1) & 7);          // source chunk (the swizzle, on the source side)
+    const int hw = p.hq * p.wq;
+    int a_yx[AROWS], a_img[AROWS];
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_img[i] = -1;
+        a_yx[i] = 0;
+        if (m < p.M) {
+            const int ni = m / hw, rem = m - ni * hw;
+            const int qy = rem / p.wq, qx = rem - qy * p.wq;
+            int by, bx;
+            if (p.mode == PFA_CONV_S2) { by = 2 * qy - 1; bx = 2 * qx - 1; }
+            else if (p.mode == PFA_CONV_S1) { by = qy - 1; bx = qx - 1; }
+            else if (p.mode == PFA_TCONV_S2) { by = qy + py; bx = qx + px; }
+            else { by = qy + 1; bx = qx + 1; }
+            a_yx[i] = (by << 16) | (bx & 0xffff);
+            a_img[i] = ni * p.hs * p.ws;
+        }
+    }
+    const int sgn = (p.mode >= PFA_TCONV_S2) ? -1 : 1;
+
+    auto stage = [&](int ks, int buf) {
+        char* abase = smem + buf * STAGE;
+        char* wbase = abase + A_BYTES;
+        const int f = ks * 8 + g;
+        const bool kval = f < p.ktot;
+        int tap, c8;
+        if (p.cpt_shift >= 0) { tap = f >> p.cpt_shift; c8 = f & (p.cpt - 1); }
+        else { tap = f / p.cpt; c8 = f - tap * p.cpt; }
+        const int c = c8 * CH;
+        int ty, tx, widx;
+        if (p.mode == PFA_TCONV_S2) {
+            ty = tap >> 1; tx = tap & 1;
+            widx = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+        } else {
+            ty = tap >> 2; tx = tap & 3;
+            widx = tap;
+        }
+        const bool first = c < p.c1;
+        const char* sbase = first ? p.src1 : p.src2;
+        const int csrc = first ? p.c1 : p.c2, cc = first ? c : c - p.c1;
+        const long long zoff = zero - sbase;       // select an OFFSET, not a pointer: stays branch-free
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int y = (a_yx[i] >> 16) + sgn * ty;
+            const int x = (int)(short)(a_yx[i] & 0xffff) + sgn * tx;
+            const bool ok = kval & (a_img[i] >= 0) & ((unsigned)y < (unsigned)p.hs) & ((unsigned)x < (unsigned)p.ws);
+            const long long off = ((long long)(a_img[i] + y * p.ws + x) * csrc + cc) * (long long)sizeof(T);
+            const char* gp = sbase + (ok ? off : zoff);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+        if (BN >= 32 || wave < 2) {
+            const long long zoffw = zero - p.w;
+#pragma unroll
+            for (int i = 0; i < WROWS; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                const bool ok = kval & (n < p.n);
+                const long long off = ((long long)(n * 16 + widx) * p.ctot + c) * (long long)sizeof(T);
+                const char* gp = p.w + (ok ? off : zoffw);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lrow = lane & 15, kk = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* abase = smem + buf * STAGE;
+        const char* wbase = abase + A_BYTES;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = kk + 4 * h;
+            typename Mma<T>::frag wf[FN], af[FM];
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int row = wn * TN + a * 16 + lrow;
+                wf[a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int row = wm * TM + b * 16 + lrow;
+                af[b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[a], af[b], acc[a][b]);
+        }
+    };
+
+    const int ks0 = split * p.kper;
+    const int ks1 = min(p.ksteps, ks0 + p.kper);
+    if (ks0 < ks1) stage(ks0, 0);
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
+        __syncthreads();              // waits vmcnt(0): stage ks has landed; everyone is done reading buf^1
+        if (ks + 1 < ks1) stage(ks + 1, buf ^ 1);
+        compute(buf);
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // lane holds D[n = .. + 4*kk + r][m = .. + lrow]
+    size_t opix[FM];
+    bool mval[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        const int m = m0 + wm * TM + b * 16 + lrow;
+        mval[b] = m < p.M;
+        opix[b] = 0;
+        if (mval[b]) {
+            if (p.mode == PFA_TCONV_S2) {
+                const int ni = m / hw, rem = m - ni * hw;
+                const int qy = rem / p.wq, qx = rem - qy * p.wq;
+                opix[b] = ((size_t)ni * p.ho + 2 * qy + py) * p.wo + 2 * qx + px;
+            } else {
+                opix[b] = (size_t)m;
+            }
+        }
+    }
+
+    if (p.splitk > 1) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+            if (nbase < p.n) {
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    if (mval[b]) *(f32x4*)(p.slab + ((size_t)split * p.npix + opix[b]) * p.n + nbase) = acc[a][b];
+            }
+        }
+        return;
+    }
+
+    if (p.bias) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bv = (nbase + r < p.n) ? p.bias[nbase + r] : 0.f;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b][r] += mval[b] ? bv : 0.f;   // rows >= M stay exact zeros
+            }
+        }
+    }
+
+    if (p.psum) {
+        // per-column sums over this tile's rows (rows >= M are exact zeros: their operands were the zero page,
+        // and BatchNorm layers carry no bias)
+        __syncthreads();
+        float* red = (float*)smem;                // [2][WM][BN]
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) { const float v = acc[a][b][r]; s += v; q += v * v; }
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+                if (lrow == 0) {
+                    const int nl = wn * TN + a * 16 + 4 * kk + r;
+                    red[wm * BN + nl] = s;
+                    red[(WM + wm) * BN + nl] = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.n) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) { s += red[i * BN + tid]; q += red[(WM + i) * BN + tid]; }
+            const size_t trow = (size_t)cls * gridDim.x + blockIdx.x;
+            p.psum[trow * p.n + n0 + tid] = s;
+            p.psq[trow * p.n + n0 + tid] = q;
+        }
+    }
+
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+        char* obase; int col, ld;
+        if (nbase < p.n1) { obase = p.out1; col = nbase; ld = p.ld1; }
+        else { obase = p.out2; col = nbase - p.n1; ld = p.ld2; }
+        if (col < ld) {
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                if (!mval[b]) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = acc[a][b][r];
+                    if (BN == 16 && p.act == PFA_ACT_TANH) v[r] = tanhf(t);          // only the 3-channel output layer
+                    else if (p.act == PFA_ACT_LRELU) v[r] = t >= 0.f ? t : t * p.slope;
+                    else if (p.act == PFA_ACT_RELU) v[r] = t > 0.f ? t : 0.f;
+                    else v[r] = t;
+                }
+                store4<T>(obase + (opix[b] * ld + col) * sizeof(T), v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- split-K finish
+// out[pix][n] = act(bias + sum_s slab[s][pix][n]); optional BatchNorm partial statistics per 64-row tile.
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slab, int splitk, int pixels, int n,
+                                                       int n1, const float* __restrict__ bias, int act, float slope,
+                                                       char* out1, int ld1, char* out2, int ld2, float* psum,
+                                                       float* psq) {
+    // block = 64 rows; thread t walks columns t, t+256, ... of each row (coalesced over n)
+    const int row0 = blockIdx.x * 64;
+    const int rows = min(64, pixels - row0);
+    // a single output also gets its pad channels [n, ld1) written (zeros), like the direct epilogue does
+    const int ncols = (n1 >= n) ? max(n, ld1) : n;
+    for (int col = threadIdx.x; col < ncols; col += 256) {
+        const bool real = col < n;
+        const float bv = (bias && real) ? bias[col] : 0.f;
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const size_t pix = row0 + r;
+            float v = bv;
+            if (real)
+                for (int k = 0; k < splitk; ++k) v += slab[((size_t)k * pixels + pix) * n + col];
+            s += v;
+            q += v * v;
+            v = apply_act(v, act, slope);
+            if (col < n1) ((T*)out1)[pix * ld1 + col] = from_f32<T>(v);
+            else ((T*)out2)[pix * ld2 + (col - n1)] = from_f32<T>(v);
+        }
+        if (psum && real) {
+            psum[(size_t)blockIdx.x * n + col] = s;
+            psq[(size_t)blockIdx.x * n + col] = q;
+        }
+    }
+}
+
+int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
+    PFA_REQUIRE(a && a->struct_size == (int)sizeof(pfa_gather_args), "pfa_gather_gemm: bad struct_size");
+    PFA_REQUIRE(a->dtype == PFA_F32 || a->dtype == PFA_BF16, "pfa_gather_gemm: bad dtype %d", a->dtype);
+    PFA_REQUIRE(a->mode >= PFA_CONV_S2 && a->mode <= PFA_CONV_S1_DGRAD, "pfa_gather_gemm: bad mode %d", a->mode);
+    const int ch = pfa_ch(a->dtype);
+    PFA_REQUIRE(a->nb > 0 && a->hq > 0 && a->wq > 0 && a->hs > 0 && a->ws > 0, "pfa_gather_gemm: empty geometry");
+    PFA_REQUIRE(a->c1 > 0 && a->c1 % ch == 0 && a->c2 >= 0 && a->c2 % ch == 0,
+                "pfa_gather_gemm: source channels (%d,%d) must be multiples of %d", a->c1, a->c2, ch);
+    PFA_REQUIRE(a->n > 0 && a->n1 > 0 && a->n1 % 4 == 0 && a->ld1 % 4 == 0 && a->ld2 % 4 == 0 && a->n1 <= a->ld1,
+                "pfa_gather_gemm: output split n=%d n1=%d ld1=%d ld2=%d", a->n, a->n1, a->ld1, a->ld2);
+    PFA_REQUIRE(a->src1 && a->w && a->out1 && (a->c2 == 0 || a->src2) && (a->ld2 == 0 || a->out2),
+                "pfa_gather_gemm: null pointer");
+    PFA_REQUIRE(a->hs < 32768 && a->ws < 32768, "pfa_gather_gemm: spatial size too large");
+    PFA_REQUIRE((a->psum == nullptr) == (a->psq == nullptr), "pfa_gather_gemm: psum/psq must come together");
+    k.src1 = (const char*)a->src1; k.src2 = (const char*)a->src2; k.w = (const char*)a->w;
+    k.out1 = (char*)a->out1; k.out2 = (char*)a->out2; k.bias = a->bias;
+    k.psum = a->psum; k.psq = a->psq; k.slab = a->slab;
+    k.mode = a->mode; k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hs = a->hs; k.ws = a->ws;
+    k.c1 = a->c1; k.c2 = a->c2; k.ctot = a->c1 + a->c2;
+    k.cpt = k.ctot / ch; k.cpt_shift = ilog2_exact(k.cpt);
+    const int ntaps = a->mode == PFA_TCONV_S2 ? 4 : 16;
+    k.ktot = ntaps * k.cpt; k.ksteps = (k.ktot + 7) / 8;
+    k.n = a->n; k.n1 = a->n1; k.ld1 = a->ld1; k.ld2 = a->ld2;
+    k.M = a->nb * a->hq * a->wq;
+    classes = a->mode == PFA_TCONV_S2 ? 4 : 1;
+    if (a->mode == PFA_TCONV_S2) { k.ho = 2 * a->hq; k.wo = 2 * a->wq; }
+    else { k.ho = a->hq; k.wo = a->wq; }
+    k.npix = a->nb * k.ho * k.wo;
+    k.splitk = a->splitk < 1 ? 1 : a->splitk;
+    if (k.splitk > k.ksteps) k.splitk = k.ksteps;
+    k.kper = (k.ksteps + k.splitk - 1) / k.splitk;
+    k.splitk = (k.ksteps + k.kper - 1) / k.kper;     // no empty slices
+    k.act = a->act; k.slope = a->slope;
+    if (k.splitk > 1) {
+        PFA_REQUIRE(a->slab && a->n % 4 == 0, "pfa_gather_gemm: split-K needs a slab and n %% 4 == 0");
+    }
+    PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
+    // geometry sanity: the source grid must be what the mode implies
+    if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
+    if (a->mode == PFA_CONV_S1) PFA_REQUIRE(a->hs == a->hq + 1 && a->ws == a->wq + 1, "pfa_gather_gemm: CONV_S1 needs hs=hq+1");
+    if (a->mode == PFA_TCONV_S2) PFA_REQUIRE(a->hs == a->hq && a->ws == a->wq, "pfa_gather_gemm: TCONV_S2 needs hs=hq");
+    if (a->mode == PFA_CONV_S1_DGRAD) PFA_REQUIRE(a->hs == a->hq - 1 && a->ws == a->wq - 1, "pfa_gather_gemm: CONV_S1_DGRAD needs hs=hq-1");
+    return 0;
+}
+
+inline int pick_bn(int n) { return n <= 16 ? 16 : (n <= 64 ? 64 : 128); }
+inline int bm_of(int bn) { return bn == 16 ? 256 : 128; }
+
+}  // namespace
+
+extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
+    GatherK k; int classes;
+    if (int rc = fill_params(a, k, classes)) return rc;
+    if (k.splitk > 1) return (k.npix + 63) / 64;
+    const int bm = bm_of(pick_bn(k.n));
+    return classes * ((k.M + bm - 1) / bm);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_gather(const GatherK& k, int classes, hipStream_t st) {
+    dim3 grid((k.M + BM - 1) / BM, (k.n + BN - 1) / BN, classes * k.splitk);
+    const size_t lds = 2 * (BM * 128 + BN * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN>), grid, dim3(256), lds, st, k);
+    PFA_LAUNCHED("k_gather_gemm");
+    return 0;
+}
+
+extern "C" int pfa_splitk_finish(const float* slab, int splitk, int pixels, int n, int n1, const float* bias, int act,
+                                 float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum,
+                                 float* psq, int* ntiles_stat, pfa_stream s) {
+    PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0, "pfa_splitk_finish: bad arguments");
+    PFA_REQUIRE(n1 >= n || out2, "pfa_splitk_finish: out2 missing");
+    const int tiles = (pixels + 63) / 64;
+    if (ntiles_stat) *ntiles_stat = tiles;
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == PFA_BF16)
+        hipLaunchKernelGGL(k_splitk_finish<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
+                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
+    else
+        hipLaunchKernelGGL(k_splitk_finish<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
+                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
+    PFA_LAUNCHED("k_splitk_finish");
+    return 0;
+}
+
+extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
+    GatherK k; int classes;
+    if (int rc = fill_params(a, k, classes)) return rc;
+    hipStream_t st = (hipStream_t)s;
+    const int bn = pick_bn(k.n);
+    int rc;
+    GatherK kk = k;
+    if (k.splitk > 1) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
+    if (a->dtype == PFA_BF16) {
+        if (bn == 128) rc = launch_gather<bf16_t, 128, 128, 2, 2>(kk, classes, st);
+        else if (bn == 64) rc = launch_gather<bf16_t, 128, 64, 2, 2>(kk, classes, st);
+        else rc = launch_gather<bf16_t, 256, 16, 4, 1>(kk, classes, st);
+    } else {
+        if (bn == 128) rc = launch_gather<float, 128, 128, 2, 2>(kk, classes, st);
+        else if (bn == 64) rc = launch_gather<float, 128, 64, 2, 2>(kk, classes, st);
+        else rc = launch_gather<float, 256, 16, 4, 1>(kk, classes, st);
+    }
+    if (rc) return rc;
+    if (k.splitk > 1) {
+        int tiles = 0;
+        // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n
+        rc = pfa_splitk_finish(k.slab, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
+                               k.out2, k.ld2, k.psum, k.psq, &tiles, s);
+        if (rc) return rc;
+        a->ntiles_stat = tiles;
+    } else {
+        a->ntiles_stat = classes * ((k.M + bm_of(bn) - 1) / bm_of(bn));
+    }
+    return 0;
+}

@@ -1,0 +1,118 @@
+// Shared host/device helpers for libpfa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <atomic>
+
+#include "../../include/pfa_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---------------------------------------------------------------- host side plumbing
+extern thread_local char g_pfa_err[512];
+extern std::atomic<uint64_t> g_pfa_launches;
+
+#define PFA_FAIL(code, ...)                                   \
+    do {                                                      \
+        snprintf(g_pfa_err, sizeof(g_pfa_err), __VA_ARGS__);  \
+        return (code);                                        \
+    } while (0)
+
+#define PFA_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) PFA_FAIL(-1, __VA_ARGS__); \
+    } while (0)
+
+// Call after every kernel launch: counts it and turns a launch error into a return code.
+#define PFA_LAUNCHED(name)                                                              \
+    do {                                                                                \
+        g_pfa_launches.fetch_add(1, std::memory_order_relaxed);                         \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess) PFA_FAIL((int)e__, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int pfa_ch(int dtype) { return dtype == PFA_BF16 ? 8 : 4; }
+static inline int pfa_esize(int dtype) { return dtype == PFA_BF16 ? 2 : 4; }
+static inline int ilog2_exact(int v) {  // log2 if power of two else -1
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+// ---------------------------------------------------------------- device helpers
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int CH = 4;   // elements per 16-byte chunk
+    static constexpr int DT = PFA_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int CH = 8;
+    static constexpr int DT = PFA_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// One 16-byte chunk of T as floats.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        f32x4 t = *(const f32x4*)p;
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *(f32x4*)p = t;
+    }
+};
+template <> struct Chunk<bf16_t> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+        *(bf16x8*)p = t;
+    }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case PFA_ACT_LRELU: return v >= 0.f ? v : v * slope;
+        case PFA_ACT_RELU: return v > 0.f ? v : 0.f;
+        case PFA_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+// derivative of the activation evaluated at its INPUT y (torch: x > 0 ? g : g*slope)
+__device__ __forceinline__ float act_grad(float y, int act, float slope) {
+    switch (act) {
+        case PFA_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case PFA_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+// 256 bytes of zeros in the code object: out-of-image taps, K tails and missing weight rows
+// point their LDS-DMA source here instead of branching.
+// (static: each translation unit carries its own copy, so no relocatable device code is needed.)
+static __device__ __attribute__((aligned(256))) uint32_t g_pfa_zero_page[64];

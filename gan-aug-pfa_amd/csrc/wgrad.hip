@@ -1,0 +1,284 @@
+// Weight-gradient implicit GEMM on MFMA.
+//
+// Replaces the weight-gradient half of autograd's backward for nn.Conv2d (models.py:177,223,230,238,243)
+// and nn.ConvTranspose2d (models.py:184,189,194) as executed by train_gan.py:62,70.
+//
+//   dw[i][tap][c] += sum_m direct[m][i] * gathered[pix(m) + tap][c]
+//
+// Conv2d:          direct = dOut  (i = Co), gathered = input (c = Ci)            -> dw[Co][16][Ci]
+// ConvTranspose2d: direct = input (i = Ci, incl. virtual concat), gathered = dOut -> dw[Ci][16][Co]
+// both with gathered pixel (qy*s-1+ky, qx*s-1+kx): the result lands directly in the memory layout of the
+// float32 master parameter (channels-last OIHW / IOHW).
+//
+// GEMM view: rows i (direct channels), columns j = flattened (tap, gathered channel), reduction over the
+// pixels m.  Both operands are stored pixel-major (NHWC), i.e. the contraction index is the SLOW axis of
+// both tiles; the tiles are staged pixel-major into LDS by LDS-DMA and handed to the MFMA through the
+// hardware transpose read ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32, one value per lane).
+// The reduction is sliced over blockIdx.z; slices combine with float32 atomics (dw is pre-zeroed).
+#include "pfa_common.h"
+
+namespace {
+
+struct WgradK {
+    const char* dir1;
+    const char* dir2;
+    const char* gat1;
+    const char* gat2;
+    float* dw;
+    int stride, nb, hq, wq, hg, wg;
+    int d1p, d1r, d2p, d2r, dp;
+    int g1p, g1r, g2p, g2r, gp, gr;
+    int M, mper;
+    unsigned magic_hw, magic_wq;
+    int jtot;        // 16 * gp
+};
+
+__device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
+    int q = (int)__umulhi((unsigned)n, magic);
+    int r = n - q * d;
+    if (r >= d) ++q;      // magic = floor(2^32/d): q is exact or one short for n < 2^31
+    return q;
+}
+
+template <typename T, int BI, int WI, int WJ>
+__global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
+    constexpr int CH = ElemTraits<T>::CH;
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int BJ = 128;
+    constexpr int KM = BF ? 64 : 32;                 // pixels per reduction step
+    constexpr int TI = BI / WI, TJ = BJ / WJ, FI = TI / 16, FJ = TJ / 16;
+    constexpr int DROWB = BI * (int)sizeof(T), GROWB = BJ * (int)sizeof(T);
+    constexpr int RCD = DROWB / 16, RCG = GROWB / 16;   // chunks per tile row
+    constexpr int D_BYTES = KM * DROWB, G_BYTES = KM * GROWB, STAGE = D_BYTES + G_BYTES;
+    constexpr int DSLOTS = KM * RCD, GSLOTS = KM * RCG;
+    constexpr int DIT = (DSLOTS + 255) / 256, GIT = GSLOTS / 256;
+    static_assert(WI * WJ == 4 && GSLOTS % 256 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave % WI, wj = wave / WI;
+    const int j0 = blockIdx.x * BJ, i0 = blockIdx.y * BI;
+    const int mbeg = blockIdx.z * p.mper;
+    const int mend = min(p.M, mbeg + p.mper);
+    const char* zero = (const char*)g_pfa_zero_page;
+
+    // swizzle of the chunk index inside a tile row (applied on the DMA source and on the reads)
+    auto swz = [](int row, int rc) -> int {
+        if (rc < 16) return 0;
+        return BF ? (row & 15) : ((row & 1) << 2);
+    };
+
+    // ---- direct operand: this thread's chunk column is fixed for the whole kernel
+    const int d_cs = tid % RCD, d_r0 = tid / RCD;
+    const int d_g = d_cs ^ swz(d_r0, RCD);
+    const char* d_base = nullptr;
+    int d_ld = 0;
+    {
+        const int ic = i0 + d_g * CH;
+        if (ic < p.d1p) { d_base = p.dir1 + (size_t)ic * sizeof(T); d_ld = p.d1p; }
+        else if (ic < p.dp) { d_base = p.dir2 + (size_t)(ic - p.d1p) * sizeof(T); d_ld = p.d2p; }
+    }
+    const bool d_active = (DSLOTS >= 256) || (tid < DSLOTS);
+    // ---- gathered operand: chunk column -> (tap, channel) fixed per thread
+    const int g_cs = tid % RCG, g_r0 = tid / RCG;
+    const int g_g = g_cs ^ swz(g_r0, RCG);
+    const char* g_base = nullptr;
+    int g_ld = 0, g_ky = 0, g_kx = 0;
+    {
+        const int jc = j0 + g_g * CH;
+        if (jc < p.jtot) {
+            const int tap = jc / p.gp, c = jc - tap * p.gp;
+            g_ky = tap >> 2; g_kx = tap & 3;
+            if (c < p.g1p) { g_base = p.gat1 + (size_t)c * sizeof(T); g_ld = p.g1p; }
+            else { g_base = p.gat2 + (size_t)(c - p.g1p) * sizeof(T); g_ld = p.g2p; }
+        }
+    }
+    const int hw = p.hq * p.wq;
+
+    auto stage = [&](int mstep, int buf) {
+        char* dbase = smem + buf * STAGE;
+        char* gbase = dbase + D_BYTES;
+        if (d_active) {
+#pragma unroll
+            for (int i = 0; i < DIT; ++i) {
+                const int mg = mstep + i * (256 / RCD) + d_r0;
+                const bool ok = d_base && mg < mend;
+                const char* gp = ok ? d_base + (size_t)mg * d_ld * sizeof(T) : zero;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(dbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const int mg = mstep + i * (256 / RCG) + g_r0;
+            bool ok = g_base && mg < mend;
+            const char* gp = zero;
+            if (ok) {
+                const int ni = fastdiv(mg, hw, p.magic_hw), rem = mg - ni * hw;
+                const int qy = fastdiv(rem, p.wq, p.magic_wq), qx = rem - qy * p.wq;
+                const int y = qy * p.stride - 1 + g_ky, x = qx * p.stride - 1 + g_kx;
+                if ((unsigned)y < (unsigned)p.hg && (unsigned)x < (unsigned)p.wg)
+                    gp = g_base + ((size_t)(ni * p.hg + y) * p.wg + x) * g_ld * sizeof(T);
+            }
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(gbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int a = 0; a < FI; ++a)
+#pragma unroll
+        for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, kk = lane >> 4;
+    auto compute = [&](int buf) {
+        const char* dbase = smem + buf * STAGE;
+        const char* gbase = dbase + D_BYTES;
+        if constexpr (BF) {
+#pragma unroll
+            for (int k32 = 0; k32 < 2; ++k32) {
+                bf16x8 af[FI], bfr[FJ];
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    // 4 pixels x 16 channels block per 16-lane group, delivered channel-major
+                    const int m = 32 * k32 + 8 * kk + 4 * e2 + (l15 >> 2);
+#pragma unroll
+                    for (int a = 0; a < FI; ++a) {
+                        const int col = wi * TI + a * 16 + 4 * (lane & 3);
+                        const int off = m * DROWB + (((col >> 3) ^ swz(m, RCD)) << 4) + ((col >> 2) & 1) * 8;
+                        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(dbase + off));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) af[a][4 * e2 + e] = t[e];
+                    }
+#pragma unroll
+                    for (int b = 0; b < FJ; ++b) {
+                        const int col = wj * TJ + b * 16 + 4 * (lane & 3);
+                        const int off = m * GROWB + (((col >> 3) ^ swz(m, RCG)) << 4) + ((col >> 2) & 1) * 8;
+                        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (__attribute__((address_space(3))) bf16x4*)(gbase + off));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bfr[b][4 * e2 + e] = t[e];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < FI; ++a)
+#pragma unroll
+                    for (int b = 0; b < FJ; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < KM / 4; ++k4) {
+                const int m = 4 * k4 + kk;
+                float af[FI], bfr[FJ];
+#pragma unroll
+                for (int a = 0; a < FI; ++a) {
+                    const int col = wi * TI + a * 16 + l15;
+                    af[a] = *(const float*)(dbase + m * DROWB + (((col >> 2) ^ swz(m, RCD)) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int b = 0; b < FJ; ++b) {
+                    const int col = wj * TJ + b * 16 + l15;
+                    bfr[b] = *(const float*)(gbase + m * GROWB + (((col >> 2) ^ swz(m, RCG)) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int a = 0; a < FI; ++a)
+#pragma unroll
+                    for (int b = 0; b < FJ; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+
+    if (mbeg < mend) stage(mbeg, 0);
+    int buf = 0;
+    for (int ms = mbeg; ms < mend; ms += KM) {
+        __syncthreads();
+        if (ms + KM < mend) stage(ms + KM, buf ^ 1);
+        compute(buf);
+        buf ^= 1;
+    }
+
+    // ---- epilogue: lane holds D[i = .. + 4*kk + r][j = .. + l15]; scatter-add into the master layout
+#pragma unroll
+    for (int b = 0; b < FJ; ++b) {
+        const int j = j0 + wj * TJ + b * 16 + l15;
+        if (j >= p.jtot) continue;
+        const int tap = j / p.gp, cp = j - tap * p.gp;
+        int creal;
+        if (cp < p.g1p) creal = cp < p.g1r ? cp : -1;
+        else creal = (cp - p.g1p) < p.g2r ? p.g1r + cp - p.g1p : -1;
+        if (creal < 0) continue;
+#pragma unroll
+        for (int a = 0; a < FI; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ip = i0 + wi * TI + a * 16 + 4 * kk + r;
+                int ireal;
+                if (ip < p.d1p) ireal = ip < p.d1r ? ip : -1;
+                else ireal = (ip - p.d1p) < p.d2r ? p.d1r + ip - p.d1p : -1;
+                if (ireal >= 0) atomicAdd(p.dw + ((size_t)ireal * 16 + tap) * p.gr + creal, acc[a][b][r]);
+            }
+        }
+    }
+}
+
+template <typename T, int BI, int WI, int WJ>
+int launch_wgrad(const WgradK& k, int msplit, hipStream_t st) {
+    constexpr int KM = sizeof(T) == 2 ? 64 : 32;
+    constexpr size_t lds = 2 * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
+    dim3 grid((k.jtot + 127) / 128, (k.dp + BI - 1) / BI, msplit);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ>), grid, dim3(256), lds, st, k);
+    PFA_LAUNCHED("k_wgrad");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
+    PFA_REQUIRE(a && a->struct_size == (int)sizeof(pfa_wgrad_args), "pfa_wgrad: bad struct_size");
+    PFA_REQUIRE(a->dtype == PFA_F32 || a->dtype == PFA_BF16, "pfa_wgrad: bad dtype");
+    const int ch = pfa_ch(a->dtype);
+    PFA_REQUIRE(a->stride == 1 || a->stride == 2, "pfa_wgrad: stride must be 1 or 2");
+    PFA_REQUIRE(a->nb > 0 && a->hq > 0 && a->wq > 0 && a->hg > 0 && a->wg > 0, "pfa_wgrad: empty geometry");
+    PFA_REQUIRE(a->d1p > 0 && a->d1p % ch == 0 && a->d2p % ch == 0 && a->g1p > 0 && a->g1p % ch == 0 && a->g2p % ch == 0,
+                "pfa_wgrad: padded channel counts must be multiples of %d", ch);
+    PFA_REQUIRE(a->d1r <= a->d1p && a->d2r <= a->d2p && a->g1r <= a->g1p && a->g2r <= a->g2p && a->d1r > 0 && a->g1r > 0,
+                "pfa_wgrad: real channel counts exceed padded ones");
+    PFA_REQUIRE(a->dir1 && a->gat1 && a->dw && (a->d2p == 0 || a->dir2) && (a->g2p == 0 || a->gat2), "pfa_wgrad: null pointer");
+    PFA_REQUIRE(a->hg == (a->hq - 1) * a->stride + 2 && a->wg == (a->wq - 1) * a->stride + 2,
+                "pfa_wgrad: gathered size %dx%d inconsistent with direct %dx%d at stride %d", a->hg, a->wg, a->hq,
+                a->wq, a->stride);
+    WgradK k;
+    k.dir1 = (const char*)a->dir1; k.dir2 = (const char*)a->dir2;
+    k.gat1 = (const char*)a->gat1; k.gat2 = (const char*)a->gat2; k.dw = a->dw;
+    k.stride = a->stride; k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hg = a->hg; k.wg = a->wg;
+    k.d1p = a->d1p; k.d1r = a->d1r; k.d2p = a->d2p; k.d2r = a->d2r; k.dp = a->d1p + a->d2p;
+    k.g1p = a->g1p; k.g1r = a->g1r; k.g2p = a->g2p; k.g2r = a->g2r; k.gp = a->g1p + a->g2p; k.gr = a->g1r + a->g2r;
+    k.M = a->nb * a->hq * a->wq;
+    const int hw = a->hq * a->wq;
+    k.magic_hw = (unsigned)(0x100000000ull / (unsigned)hw);
+    k.magic_wq = (unsigned)(0x100000000ull / (unsigned)a->wq);
+    if (hw == 1) k.magic_hw = 0xffffffffu;
+    if (a->wq == 1) k.magic_wq = 0xffffffffu;
+    k.jtot = 16 * k.gp;
+    const int km = a->dtype == PFA_BF16 ? 64 : 32;
+    int msplit = a->msplit < 1 ? 1 : a->msplit;
+    int steps = (k.M + km - 1) / km;
+    if (msplit > steps) msplit = steps;
+    int sper = (steps + msplit - 1) / msplit;
+    msplit = (steps + sper - 1) / sper;
+    k.mper = sper * km;
+    hipStream_t st = (hipStream_t)s;
+    const bool small_i = k.dp <= 16;
+    if (a->dtype == PFA_BF16)
+        return small_i ? launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st) : launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st);
+    return small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);
+}

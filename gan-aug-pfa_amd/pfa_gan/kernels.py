@@ -1,0 +1,252 @@
+"""Tensor-level wrappers over the C ABI (one Python function per libpfa_hip entry point).
+
+torch is used for device memory and the current HIP stream only; every arithmetic kernel is in
+libpfa_hip.so.  Activations are NHWC tensors [B, H, W, Cp] (bf16 or f32) whose channel count is
+padded to 16 bytes; pad lanes are zero.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, BF16, CONV_S1, CONV_S1_DGRAD, CONV_S2, F32, TCONV_S2,
+                   GatherArgs, WgradArgs, check, lib)
+
+SLOPE = 0.2          # nn.LeakyReLU(0.2): models.py:178,223,232,240
+BN_EPS = 1e-5        # nn.BatchNorm2d defaults: models.py:179,181,231,239
+BN_MOMENTUM = 0.1
+
+
+def dt_code(dtype):
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {dtype}")
+
+
+def ch_of(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def pad_ch(c, dtype):
+    ch = ch_of(dtype)
+    return (c + ch - 1) // ch * ch
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PfaError("libpfa_hip kernels need GPU tensors; got a CPU tensor")
+
+
+class Workspace:
+    """Caller-owned scratch the library never allocates itself (SURVEY 8b 'Ownership')."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    def get(self, name, numel, dtype=torch.float32):
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < numel or buf.dtype != dtype:
+            buf = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._bufs[name] = buf
+        return buf
+
+
+# ------------------------------------------------------------------------------- gather GEMM
+def choose_splitk(mode, M, n, ctot, dtype):
+    """Slice K over extra workgroups when the output grid alone cannot fill 256 CUs
+    (the bottleneck layers at 8x8 and below are weight-bandwidth bound, SURVEY 7 'Hard parts')."""
+    bn = 16 if n <= 16 else (64 if n <= 64 else 128)
+    bm = 256 if bn == 16 else 128
+    classes = 4 if mode == TCONV_S2 else 1
+    blocks = math.ceil(M / bm) * math.ceil(n / bn) * classes
+    ksteps = math.ceil((4 if mode == TCONV_S2 else 16) * (ctot // ch_of(dtype)) / 8)
+    if blocks >= 192 or ksteps < 8 or n % 4:
+        return 1
+    return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
+
+
+def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None):
+    """out = act(bias + implicit_gemm(srcs, w)).  srcs/outs: lists of 1 or 2 NHWC tensors.
+
+    grid = (nb, hq, wq) position grid.  Returns (psum, psq, ntiles) views when stats=True.
+    """
+    _require_cuda(*srcs, w, *outs)
+    dtype = srcs[0].dtype
+    a = GatherArgs()
+    a.struct_size = ctypes.sizeof(GatherArgs)
+    a.mode, a.dtype = mode, dt_code(dtype)
+    a.nb, a.hq, a.wq = grid
+    a.hs, a.ws = srcs[0].shape[1], srcs[0].shape[2]
+    a.c1 = srcs[0].shape[3]
+    a.c2 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    a.n = n
+    a.ld1 = outs[0].shape[3]
+    a.ld2 = outs[1].shape[3] if len(outs) > 1 else 0
+    a.n1 = outs[0].shape[3]
+    a.act, a.slope = act, SLOPE
+    M = grid[0] * grid[1] * grid[2]
+    a.splitk = choose_splitk(mode, M, n, a.c1 + a.c2, dtype) if splitk is None else splitk
+    a.src1, a.src2 = ptr(srcs[0]), ptr(srcs[1]) if len(srcs) > 1 else None
+    a.w, a.bias = ptr(w), ptr(bias)
+    a.out1, a.out2 = ptr(outs[0]), ptr(outs[1]) if len(outs) > 1 else None
+    npix = outs[0].shape[0] * outs[0].shape[1] * outs[0].shape[2]
+    if a.splitk > 1:
+        a.slab = ptr(ws.get("slab", a.splitk * npix * n))
+    psum = psq = None
+    if stats:
+        tiles = max(math.ceil(npix / 64), 4 * math.ceil(M / 128)) + 4
+        psum = ws.get("psum", tiles * n)
+        psq = ws.get("psq", tiles * n)
+        a.psum, a.psq = ptr(psum), ptr(psq)
+    check(lib().pfa_gather_gemm(ctypes.byref(a), stream()), "pfa_gather_gemm")
+    return (psum, psq, a.ntiles_stat) if stats else None
+
+
+def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None):
+    """dw[i][tap][c] += sum_m direct[m][i] * gathered[pix(m)+tap][c] (float32, atomically accumulated).
+
+    direct/gathered: lists of 1-2 NHWC tensors; dreal/greal: real channel counts per part.
+    """
+    _require_cuda(*direct, *gathered, dw)
+    a = WgradArgs()
+    a.struct_size = ctypes.sizeof(WgradArgs)
+    a.dtype, a.stride = dt_code(direct[0].dtype), stride
+    a.nb, a.hq, a.wq = direct[0].shape[:3]
+    a.hg, a.wg = gathered[0].shape[1:3]
+    a.d1p, a.d1r = direct[0].shape[3], dreal[0]
+    a.d2p, a.d2r = (direct[1].shape[3], dreal[1]) if len(direct) > 1 else (0, 0)
+    a.g1p, a.g1r = gathered[0].shape[3], greal[0]
+    a.g2p, a.g2r = (gathered[1].shape[3], greal[1]) if len(gathered) > 1 else (0, 0)
+    if msplit is None:
+        km = 64 if direct[0].dtype == torch.bfloat16 else 32
+        M = a.nb * a.hq * a.wq
+        tiles = math.ceil(16 * (a.g1p + a.g2p) / 128) * math.ceil((a.d1p + a.d2p) / 128)
+        msplit = max(1, min(math.ceil(M / km / 4), math.ceil(768 / tiles)))
+    a.msplit = msplit
+    a.dir1, a.dir2 = ptr(direct[0]), ptr(direct[1]) if len(direct) > 1 else None
+    a.gat1, a.gat2 = ptr(gathered[0]), ptr(gathered[1]) if len(gathered) > 1 else None
+    a.dw = ptr(dw)
+    check(lib().pfa_wgrad(ctypes.byref(a), stream()), "pfa_wgrad")
+
+
+# ------------------------------------------------------------------------------- BatchNorm
+def bn_finalize(psum, psq, ntiles, c, count, gamma, beta, running_mean, running_var, nbt, scale, shift, mean, invstd,
+                repeats=1):
+    check(lib().pfa_bn_finalize(ptr(psum), ptr(psq), ntiles, c, float(count), ptr(gamma), ptr(beta), BN_EPS,
+                                BN_MOMENTUM, repeats, ptr(running_mean), ptr(running_var), ptr(nbt), ptr(scale),
+                                ptr(shift), ptr(mean), ptr(invstd), stream()), "pfa_bn_finalize")
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, scale, shift):
+    check(lib().pfa_bn_eval_coeffs(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_EPS,
+                                   running_mean.numel(), ptr(scale), ptr(shift), stream()), "pfa_bn_eval_coeffs")
+
+
+def rows_of(t):
+    return t.shape[0] * t.shape[1] * t.shape[2]
+
+
+def bn_act(raw, scale, shift, out_l=None, out_r=None):
+    _require_cuda(raw)
+    check(lib().pfa_bn_act(ptr(raw), rows_of(raw), raw.shape[3], dt_code(raw.dtype), ptr(scale), ptr(shift), SLOPE,
+                           ptr(out_l), ptr(out_r), stream()), "pfa_bn_act")
+
+
+def bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, ws):
+    """dy = act1'(y)*g1 + act2'(y)*g2; returns (part, ntiles) or (None, 0) when mean is None."""
+    rows, c = rows_of(raw), raw.shape[3]
+    part = None
+    if mean is not None:
+        tiles = lib().pfa_bn_bwd_tiles(rows, c, dt_code(raw.dtype))
+        if tiles < 0:
+            raise _lib.PfaError(f"BatchNorm backward: channel count {c} unsupported (c/chunk must divide 256)")
+        part = ws.get("bnpart", 2 * tiles * c)
+    nt = ctypes.c_int(0)
+    check(lib().pfa_bn_bwd_reduce(ptr(raw), rows, c, dt_code(raw.dtype), ptr(scale), ptr(shift), ptr(mean),
+                                  ptr(invstd), ptr(g1), act1, ptr(g2), act2, SLOPE, ptr(dy), ptr(part),
+                                  ctypes.byref(nt), stream()), "pfa_bn_bwd_reduce")
+    return part, nt.value
+
+
+def bn_bwd_finalize(part, ntiles, c, count, gamma, mean, invstd, dgamma, dbeta, coef):
+    check(lib().pfa_bn_bwd_finalize(ptr(part), ntiles, c, float(count), ptr(gamma), ptr(mean), ptr(invstd),
+                                    ptr(dgamma), ptr(dbeta), ptr(coef), stream()), "pfa_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dy, raw, coef, dr):
+    check(lib().pfa_bn_bwd_apply(ptr(dy), ptr(raw), rows_of(raw), raw.shape[3], dt_code(raw.dtype), ptr(coef),
+                                 ptr(dr), stream()), "pfa_bn_bwd_apply")
+
+
+# ------------------------------------------------------------------------------- losses
+def bce_logits(logits, target, lscale, gscale, loss_acc, dlogits):
+    check(lib().pfa_bce_logits(ptr(logits), rows_of(logits), logits.shape[3], dt_code(logits.dtype), float(target),
+                               float(lscale), float(gscale), ptr(loss_acc), ptr(dlogits), stream()), "pfa_bce_logits")
+
+
+def l1_tanh_bwd(fake, real, c_real, dgan, dgan_off, lam, loss_acc, dpre):
+    check(lib().pfa_l1_tanh_bwd(ptr(fake), ptr(real), rows_of(fake), fake.shape[3], c_real, dt_code(fake.dtype),
+                                ptr(dgan), dgan.shape[3] if dgan is not None else 0, dgan_off, float(lam),
+                                ptr(loss_acc), ptr(dpre), stream()), "pfa_l1_tanh_bwd")
+
+
+def colsum(x, out, ws, c_out=None):
+    """out[j] += sum over pixels of x[..., j], j < c_out (default: len(out))."""
+    rows, c = rows_of(x), x.shape[3]
+    scratch = ws.get("colsum", lib().pfa_colsum_ws(rows, c))
+    check(lib().pfa_colsum(ptr(x), rows, c, out.numel() if c_out is None else c_out, dt_code(x.dtype), ptr(out),
+                           ptr(scratch), stream()), "pfa_colsum")
+
+
+# ------------------------------------------------------------------------------- Adam, shadows, layout
+def adam(p, g, m, v, lr, b1, b2, eps, step, step_dev=None, grad_scale=1.0):
+    check(lib().pfa_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, int(step), ptr(step_dev),
+                         float(grad_scale), stream()), "pfa_adam")
+
+
+def adam_tick(step_dev):
+    check(lib().pfa_adam_tick(ptr(step_dev), stream()), "pfa_adam_tick")
+
+
+def weight_shadow(master, rows, c1r, c1p, c2r, c2p, rows_p, same, tr):
+    dtype = same.dtype if same is not None else tr.dtype
+    check(lib().pfa_weight_shadow(ptr(master), rows, c1r, c1p, c2r, c2p, rows_p, dt_code(dtype), ptr(same), ptr(tr),
+                                  stream()), "pfa_weight_shadow")
+
+
+def pack_nhwc(x, dtype, out=None):
+    """NCHW float32 -> NHWC `dtype` with the channel count padded to 16 bytes."""
+    _require_cuda(x)
+    n, c, h, w = x.shape
+    x = x.contiguous().float()
+    cp = pad_ch(c, dtype)
+    if out is None:
+        out = torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    check(lib().pfa_pack_nhwc(ptr(x), n, c, h, w, cp, dt_code(dtype), ptr(out), stream()), "pfa_pack_nhwc")
+    return out
+
+
+def unpack_nchw(x, c, out=None):
+    """NHWC (padded) -> NCHW float32, real channels only."""
+    n, h, w, cp = x.shape
+    if out is None:
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib().pfa_unpack_nchw(ptr(x), n, c, h, w, cp, dt_code(x.dtype), ptr(out), stream()), "pfa_unpack_nchw")
+    return out
+
+
+def fill_zero(t):
+    check(lib().pfa_fill_zero(ptr(t), t.numel() * t.element_size(), stream()), "pfa_fill_zero")

@@ -1,0 +1,186 @@
+/*
+ * libpfa_hip.so - C ABI of the MI355X (gfx950) kernels behind the Pix2Pix GAN step.
+ *
+ * The reference (Affi-Amine/GAN-AUG-PFA) has no FFI layer: its hot path calls PyTorch
+ * operators from Python (models.py:177-247, train_gan.py:42-71).  This header is the
+ * boundary a maintainer binds instead: one entry point per operator
+ * family, raw device pointers + sizes + a hipStream_t, no torch types.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, a negative value for an argument / shape error
+ *    detected before launch, or a positive hipError_t.  pfa_last_error_string() gives the
+ *    message (thread local).  No exception crosses the ABI.
+ *  - Launch-only: no hipMalloc / hipFree / synchronisation inside; every buffer (workspaces
+ *    included) is owned by the caller and must outlive the stream work.  All launches are
+ *    ordered on the stream argument and are hipGraph-capturable.
+ *  - Activations are NHWC ("channels last"), element type pfa_dtype, channel counts padded
+ *    to PFA_CH(dtype) = 16 bytes / sizeof(element) (8 for bf16, 4 for f32); pad lanes hold 0.
+ *  - Convolution weights for the kernels ("shadows") are [rows][16 taps][channels] with the
+ *    contraction channel contiguous; tap = ky*4 + kx.  Master parameters stay float32 in the
+ *    reference's OIHW / IOHW logical shape (channels-last memory), see pfa_weight_shadow.
+ */
+#ifndef PFA_HIP_H
+#define PFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pfa_stream;                 /* hipStream_t */
+
+enum pfa_dtype { PFA_F32 = 0, PFA_BF16 = 1 };
+#define PFA_CH(dtype) ((dtype) == PFA_BF16 ? 8 : 4)
+
+enum pfa_act { PFA_ACT_NONE = 0, PFA_ACT_LRELU = 1, PFA_ACT_RELU = 2, PFA_ACT_TANH = 3 };
+
+/* Geometry of an implicit-GEMM gather (no im2col buffer is ever materialised). */
+enum pfa_gather_mode {
+    PFA_CONV_S2 = 0,        /* nn.Conv2d(k4,s2,p1) forward (models.py:177,223,230); also ConvTranspose2d dgrad */
+    PFA_CONV_S1 = 1,        /* nn.Conv2d(k4,s1,p1) forward (models.py:238,243)                                   */
+    PFA_TCONV_S2 = 2,       /* nn.ConvTranspose2d(k4,s2,p1) forward (models.py:184,189,194) as 4 output-parity   */
+                            /* 2x2-tap convolutions; also the dgrad of the stride-2 Conv2d                      */
+    PFA_CONV_S1_DGRAD = 3   /* dgrad of the stride-1 Conv2d                                                      */
+};
+
+int pfa_version(void);
+const char* pfa_last_error_string(void);
+/* Number of kernel launches issued by this process through the library (tests use it to
+ * prove the HIP path, not a fallback, produced a result). */
+uint64_t pfa_launch_count(void);
+
+/* ------------------------------------------------------------------ implicit GEMM, MFMA
+ * out[pix(m)][n] = act( bias[n] + sum_{tap,c} src[pix(m)+tap][c] * w[n][tap][c] )
+ * Replaces: Conv2d / ConvTranspose2d forward and their input gradients.
+ * rows m enumerate the position grid [nb][hq][wq]; for PFA_TCONV_S2 the grid is the SOURCE
+ * grid and each of the 4 parity classes writes output pixel (2qy+py, 2qx+px).
+ * The source may be a virtual concat [src1 (c1 ch) | src2 (c2 ch)] (torch.cat of models.py:208
+ * is never materialised); the output columns may be split [out1 (n1 cols) | out2].
+ */
+typedef struct pfa_gather_args {
+    int32_t struct_size;
+    int32_t mode, dtype;
+    int32_t nb, hq, wq;          /* position grid                                   */
+    int32_t hs, ws;              /* source spatial size                             */
+    int32_t c1, c2;              /* padded source channels, multiples of PFA_CH     */
+    int32_t n;                   /* GEMM N = rows of w that exist                   */
+    int32_t n1;                  /* columns [0,n1) -> out1, [n1,..) -> out2         */
+    int32_t ld1, ld2;            /* channel stride (padded channels) of out1 / out2 */
+    int32_t act;                 /* pfa_act applied after bias                      */
+    float slope;                 /* LeakyReLU slope                                 */
+    int32_t splitk;              /* 1, or number of K slices (partials -> slab)     */
+    int32_t ntiles_stat;         /* out: rows of psum/psq written (may be NULL use) */
+    const void* src1;
+    const void* src2;
+    const void* w;               /* [n][16][c1+c2]                                  */
+    const float* bias;           /* [n] or NULL                                     */
+    void* out1;
+    void* out2;
+    float* psum;                 /* optional BatchNorm partial sums   [tiles][n]    */
+    float* psq;                  /* optional partial sums of squares  [tiles][n]    */
+    float* slab;                 /* splitk>1: float32 [splitk][pixels][n] workspace */
+} pfa_gather_args;
+
+/* Tiles of partial statistics a call will write (rows of psum/psq) for this geometry. */
+int pfa_gather_stat_tiles(const pfa_gather_args* a);
+int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s);
+
+/* Sum split-K slabs, add bias, emit statistics partials, activate, store.  `pixels` rows. */
+int pfa_splitk_finish(const float* slab, int splitk, int pixels, int n, int n1, const float* bias, int act,
+                      float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
+                      int* ntiles_stat, pfa_stream s);
+
+/* ------------------------------------------------------------------ weight gradient, MFMA
+ * dw[i][tap][c] (+)= sum_m direct[m][i] * gathered[pix(m)+tap][c]     (float32 accumulate)
+ * Replaces: autograd's weight gradient of Conv2d (direct = dOut, gathered = input) and of
+ * ConvTranspose2d (direct = input incl. the virtual concat, gathered = dOut).
+ * Gathered pixel = (qy*stride - 1 + ky, qx*stride - 1 + kx).  dw is laid out like the
+ * float32 master parameter: [i_real][16][c_real] (pad channels of either side are skipped).
+ */
+typedef struct pfa_wgrad_args {
+    int32_t struct_size;
+    int32_t dtype, stride;
+    int32_t nb, hq, wq;          /* direct operand grid (reduction rows)                       */
+    int32_t hg, wg;              /* gathered operand spatial size                              */
+    int32_t d1p, d1r, d2p, d2r;  /* direct channels: padded / real, for src1 and src2 (d2*=0)  */
+    int32_t g1p, g1r, g2p, g2r;  /* gathered channels likewise                                 */
+    int32_t msplit;              /* number of slices of the reduction (>=1)                    */
+    int32_t reserved;
+    const void* dir1;
+    const void* dir2;
+    const void* gat1;
+    const void* gat2;
+    float* dw;                   /* [d1r+d2r][16][g1r+g2r], must be zeroed by the caller       */
+} pfa_wgrad_args;
+int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s);
+
+/* ------------------------------------------------------------------ BatchNorm2d (training)
+ * Replaces nn.BatchNorm2d (models.py:179,181,231,239): eps 1e-5, momentum 0.1, biased batch
+ * variance for normalisation, unbiased for running_var.  Statistics arrive as per-tile
+ * partial sums written by the GEMM epilogue; `repeats` applies the running-buffer update that
+ * many times (the reference runs the generator forward twice per step, train_gan.py:56,65).
+ */
+int pfa_bn_finalize(const float* psum, const float* psq, int ntiles, int c, double count, const float* gamma,
+                    const float* beta, float eps, float momentum, int repeats, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* scale, float* shift, float* mean,
+                    float* invstd, pfa_stream s);
+/* Eval mode (generate_synthetic_data.py:55): scale/shift from the running buffers. */
+int pfa_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int c, float* scale, float* shift, pfa_stream s);
+/* y = scale*raw + shift (identity when scale==NULL); out_l = LeakyReLU(y), out_r = ReLU(y); either may be NULL. */
+int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const float* scale, const float* shift, float slope,
+               void* out_l, void* out_r, pfa_stream s);
+/* dy = act1'(y)*g1 (+ act2'(y)*g2), y = scale*raw+shift; partial sums of dy and dy*xhat -> part[2][tiles][c].
+ * With mean==NULL (no norm after this conv) only dy is written (then dy IS the conv-output gradient). */
+int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const void* g1, int act1, const void* g2, int act2,
+                      float slope, void* dy, float* part, int* ntiles, pfa_stream s);
+/* Rows of `part` (per half) a pfa_bn_bwd_reduce call over [rows][c] writes; -1 if c is unsupported. */
+int pfa_bn_bwd_tiles(int64_t rows, int c, int dtype);
+int pfa_bn_bwd_finalize(const float* part, int ntiles, int c, double count, const float* gamma, const float* mean,
+                        const float* invstd, float* dgamma, float* dbeta, float* coef, pfa_stream s);
+/* dr = coef[0][c]*dy + coef[1][c]*raw + coef[2][c]   (may run in place on dy) */
+int pfa_bn_bwd_apply(const void* dy, const void* raw, int64_t rows, int c, int dtype, const float* coef, void* dr,
+                     pfa_stream s);
+
+/* ------------------------------------------------------------------ losses (train_gan.py:42-43,58-69) */
+/* BCEWithLogitsLoss, mean over `count` logits (channel 0 of a [count][ld] tensor), constant target.
+ * loss_acc[0] += lscale * mean_loss; dlogits = gscale * (sigmoid(x)-target)/count (pad channels 0). */
+int pfa_bce_logits(const void* logits, int64_t count, int ld, int dtype, float target, float lscale, float gscale,
+                   float* loss_acc, void* dlogits, pfa_stream s);
+/* L1Loss mean over count*c_real elements + Tanh backward, fused:
+ * d = (dgan ? dgan[.., dgan_off + c] : 0) + lambda * sign(fake-real)/(count*c_real); dpre = d*(1-fake^2);
+ * loss_acc[0] += lambda * mean|fake-real|. */
+int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                    const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
+                    pfa_stream s);
+/* out[j] += sum_rows x[row][j] for j < c_out <= c (bias gradients; accumulates like every gradient output).
+ * ws: >= pfa_colsum_ws(rows,c) floats. */
+size_t pfa_colsum_ws(int64_t rows, int c);
+int pfa_colsum(const void* x, int64_t rows, int c, int c_out, int dtype, float* out, float* ws, pfa_stream s);
+
+/* ------------------------------------------------------------------ Adam (train_gan.py:140-141) */
+/* torch.optim.Adam, weight_decay 0, amsgrad off, over one flat float32 arena.  `step` is the 1-based
+ * step count of THIS update; when step_dev != NULL the count is read from device memory instead
+ * (hipGraph replay) after being incremented by pfa_adam_tick. */
+int pfa_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             int step, const int32_t* step_dev, float grad_scale, pfa_stream s);
+int pfa_adam_tick(int32_t* step_dev, pfa_stream s);
+
+/* ------------------------------------------------------------------ layout / precision plumbing */
+/* Master float32 parameter [rows][16][c1r+c2r] (channels-last memory of the OIHW / IOHW tensor) ->
+ *   same: [rows][16][c1p+c2p] in `dtype` (pad channels zero), and
+ *   tr  : [c1p+c2p][16][rows_p] in `dtype` (rows of pad channels zero).   Either may be NULL. */
+int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p, int c2r, int c2p, int rows_p, int dtype,
+                      void* same, void* tr, pfa_stream s);
+/* NCHW float32 [n][c][h][w] <-> NHWC `dtype` [n][h][w][cp] (cp >= c, pad lanes zero / ignored). */
+int pfa_pack_nhwc(const float* src, int n, int c, int h, int w, int cp, int dtype, void* dst, pfa_stream s);
+int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dtype, float* dst, pfa_stream s);
+int pfa_fill_zero(void* p, size_t bytes, pfa_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFA_HIP_H */

@@ -1,0 +1,346 @@
+"""-m gpu: every libpfa_hip kernel against the numpy oracle (oracle/ops.py), through the C ABI.
+
+f32 mode must sit far inside the north-star gate (1e-3 abs / 1e-2 rel); bf16 mode is checked on
+bf16-representable operands (products exact in f32, fp32 accumulation, one bf16 rounding of the result).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fill, ops
+from pfa_gan import _lib, kernels as K
+from gpu_util import DTYPES, DT_IDS, close, from_nhwc, master_of, rnd, shadows, to_nhwc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ws():
+    return K.Workspace(torch.device("cuda"))
+
+
+def test_library_is_the_path():
+    assert _lib.lib().pfa_version() >= 100
+    before = _lib.launch_count()
+    x = torch.zeros(1, 3, 4, 4, device="cuda")
+    K.pack_nhwc(x, torch.bfloat16)
+    assert _lib.launch_count() == before + 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+def test_pack_unpack_and_shadows(dtype):
+    x = rnd(fill.uniform("pk.x", (2, 3, 5, 7)), dtype)
+    t = to_nhwc(x, dtype)
+    assert t.shape == (2, 5, 7, K.pad_ch(3, dtype))
+    assert float(t[..., 3:].abs().max()) == 0.0
+    np.testing.assert_array_equal(from_nhwc(t, 3), x)
+    w = rnd(fill.uniform("pk.w", (10, 6, 4, 4)), dtype)
+    cp = K.pad_ch(3, dtype)
+    same, tr = shadows(w, dtype, cparts=[(3, cp), (3, cp)])
+    torch.cuda.synchronize()
+    ref = np.zeros((10, 16, 2 * cp), np.float32)
+    m = w.transpose(0, 2, 3, 1).reshape(10, 16, 6)
+    ref[:, :, :3] = m[:, :, :3]
+    ref[:, :, cp:cp + 3] = m[:, :, 3:]
+    np.testing.assert_array_equal(same.float().cpu().numpy(), ref)
+    rp = K.pad_ch(10, dtype)
+    ref_tr = np.zeros((2 * cp, 16, rp), np.float32)
+    ref_tr[:, :, :10] = ref.transpose(2, 1, 0)
+    np.testing.assert_array_equal(tr.float().cpu().numpy(), ref_tr)
+
+
+# ---------------------------------------------------------------------------- forward convolutions
+CONV_FWD = [  # name, N, cin parts, H, W, Co, stride, bias, act, splitk
+    ("e1_like", 2, [3], 16, 16, 16, 2, False, K.ACT_NONE, None),
+    ("c1_like_cat", 2, [3, 3], 16, 16, 64, 2, True, K.ACT_LRELU, None),
+    ("mid_16_32", 2, [16], 8, 8, 32, 2, False, K.ACT_NONE, None),
+    ("bn128_tiles", 2, [64], 32, 32, 128, 2, False, K.ACT_NONE, 1),
+    ("bn128_edge", 3, [32], 10, 14, 136, 2, False, K.ACT_NONE, 1),
+    ("splitk4", 2, [64], 16, 16, 64, 2, False, K.ACT_RELU, 4),
+    ("auto_split_deep", 2, [128], 4, 4, 128, 2, False, K.ACT_NONE, None),
+    ("s1_c4_like", 2, [32], 9, 9, 64, 1, False, K.ACT_NONE, None),
+    ("s1_odd31", 1, [16], 32, 32, 32, 1, False, K.ACT_NONE, 1),
+    ("s1_c5_like", 2, [64], 7, 6, 1, 1, True, K.ACT_NONE, None),
+    ("one_by_one", 2, [16], 2, 2, 16, 2, False, K.ACT_NONE, None),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", CONV_FWD, ids=[c[0] for c in CONV_FWD])
+def test_conv_forward(case, dtype, ws):
+    name, n, cins, h, w, co, stride, bias, act, splitk = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".x", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".w", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    b = fill.uniform(name + ".b", (co,), -0.5, 0.5) if bias else None
+    want = ops.conv2d_fwd(x, wt, b, stride)
+    raw = want.copy()
+    if act == K.ACT_LRELU:
+        want = ops.leaky_relu(want)
+    elif act == K.ACT_RELU:
+        want = ops.relu(want)
+    parts, srcs, o = [], [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        parts.append((c, K.pad_ch(c, dtype)))
+        o += c
+    same, _ = shadows(wt, dtype, cparts=parts, want=("same",))
+    ho, wo = want.shape[2:]
+    out = torch.full((n, ho, wo, K.pad_ch(co, dtype)), 7.0, dtype=dtype, device="cuda")
+    bt = torch.from_numpy(b).cuda() if bias else None
+    before = _lib.launch_count()
+    st = K.gather_gemm(K.CONV_S2 if stride == 2 else K.CONV_S1, srcs, same, co, [out], (n, ho, wo), ws, bias=bt,
+                       act=act, stats=True, splitk=splitk)
+    assert _lib.launch_count() > before
+    close(from_nhwc(out, co), want, dtype, name)
+    if K.pad_ch(co, dtype) > co:
+        assert float(out[..., co:].float().abs().max()) == 0.0, "pad channels must be written as zeros"
+    psum, psq, nt = st
+    torch.cuda.synchronize()
+    s = psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
+    q = psq[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
+    close(s, raw.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
+          scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
+    close(q, (raw.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
+
+
+CONVT_FWD = [  # name, N, cin parts, H, W, Co, bias, act, splitk
+    ("d7_like", 2, [16], 1, 1, 16, False, K.ACT_NONE, None),
+    ("mid_cat", 2, [16, 16], 4, 4, 8, False, K.ACT_NONE, None),
+    ("d1_like", 2, [16, 16], 8, 8, 3, True, K.ACT_TANH, None),
+    ("rect", 1, [8], 3, 5, 24, False, K.ACT_NONE, 1),
+    ("big", 2, [64, 64], 16, 16, 64, False, K.ACT_NONE, 1),
+    ("deep_split", 2, [128], 2, 2, 128, False, K.ACT_NONE, None),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", CONVT_FWD, ids=[c[0] for c in CONVT_FWD])
+def test_convT_forward(case, dtype, ws):
+    name, n, cins, h, w, co, bias, act, splitk = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".x", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".w", (ci, co, 4, 4), -0.25, 0.25), dtype)
+    b = fill.uniform(name + ".b", (co,), -0.5, 0.5) if bias else None
+    raw = ops.convT2d_fwd(x, wt, b)
+    want = np.tanh(raw) if act == K.ACT_TANH else raw
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    # master [Ci][16][Co]; the forward operand is its transpose [Co_p][16][Ci]
+    _, tr = shadows(wt, dtype, want=("tr",))
+    out = torch.full((n, 2 * h, 2 * w, K.pad_ch(co, dtype)), 7.0, dtype=dtype, device="cuda")
+    bt = torch.from_numpy(b).cuda() if bias else None
+    st = K.gather_gemm(K.TCONV_S2, srcs, tr, co, [out], (n, h, w), ws, bias=bt, act=act, stats=True, splitk=splitk)
+    close(from_nhwc(out, co), want, dtype, name)
+    psum, psq, nt = st
+    torch.cuda.synchronize()
+    s = psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
+    close(s, raw.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
+          scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
+
+
+# ---------------------------------------------------------------------------- input gradients
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", [("s2", 2, 16, 8, 8, 32, 2), ("s2_c1like", 2, 6, 16, 16, 64, 2),
+                                  ("s1", 2, 32, 9, 9, 64, 1), ("s1_co1", 2, 64, 7, 6, 1, 1),
+                                  ("s2_big", 2, 64, 32, 32, 128, 2)], ids=lambda c: c[0])
+def test_conv_dgrad(case, dtype, ws):
+    name, n, ci, h, w, co, stride = case
+    x = fill.uniform(name + ".dx.x", (n, ci, h, w))
+    wt = rnd(fill.uniform(name + ".dx.w", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    ho, wo = (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+    dy = rnd(fill.uniform(name + ".dx.dy", (n, co, ho, wo)), dtype)
+    want, _, _ = ops.conv2d_bwd(x, wt, dy, stride)
+    _, tr = shadows(wt, dtype, want=("tr",))           # [Ci_p][16][Co_p]
+    dyt = to_nhwc(dy, dtype)
+    out = torch.full((n, h, w, K.pad_ch(ci, dtype)), 7.0, dtype=dtype, device="cuda")
+    if stride == 2:
+        K.gather_gemm(K.TCONV_S2, [dyt], tr, ci, [out], (n, ho, wo), ws)
+    else:
+        K.gather_gemm(K.CONV_S1_DGRAD, [dyt], tr, ci, [out], (n, h, w), ws)
+    close(from_nhwc(out, ci), want, dtype, name)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", [("single", 2, [16], 4, 4, 8), ("cat_split", 2, [16, 32], 4, 4, 16),
+                                  ("co3", 2, [16, 16], 8, 8, 3)], ids=lambda c: c[0])
+def test_convT_dgrad(case, dtype, ws):
+    name, n, cins, h, w, co = case
+    ci = sum(cins)
+    x = fill.uniform(name + ".tdx.x", (n, ci, h, w))
+    wt = rnd(fill.uniform(name + ".tdx.w", (ci, co, 4, 4), -0.25, 0.25), dtype)
+    dy = rnd(fill.uniform(name + ".tdx.dy", (n, co, 2 * h, 2 * w)), dtype)
+    want, _, _ = ops.convT2d_bwd(x, wt, dy)
+    same, _ = shadows(wt, dtype, want=("same",))        # [Ci][16][Co_p]
+    dyt = to_nhwc(dy, dtype)
+    outs = [torch.full((n, h, w, c), 7.0, dtype=dtype, device="cuda") for c in cins]
+    K.gather_gemm(K.CONV_S2, [dyt], same, ci, outs, (n, h, w), ws)
+    got = np.concatenate([from_nhwc(o, c) for o, c in zip(outs, cins)], axis=1)
+    close(got, want, dtype, name)
+
+
+# ---------------------------------------------------------------------------- weight gradients
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", [("s2", 2, [16], 8, 8, 32, 2, None), ("s2_ci3", 2, [3], 16, 16, 16, 2, None),
+                                  ("s2_cat33", 2, [3, 3], 16, 16, 64, 2, None), ("s1", 2, [32], 9, 9, 64, 1, None),
+                                  ("s1_co1", 2, [64], 7, 6, 1, 1, None), ("s2_msplit", 4, [64], 32, 32, 128, 2, 5),
+                                  ("s2_co136", 1, [16], 8, 8, 136, 2, 1)], ids=lambda c: c[0])
+def test_conv_wgrad(case, dtype, ws):
+    name, n, cins, h, w, co, stride, msplit = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".dw.x", (n, ci, h, w)), dtype)
+    wt = fill.uniform(name + ".dw.w", (co, ci, 4, 4))
+    ho, wo = (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+    dy = rnd(fill.uniform(name + ".dw.dy", (n, co, ho, wo)), dtype)
+    _, want, _ = ops.conv2d_bwd(x, wt, dy, stride, need_dx=False)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    dw = torch.zeros((co, 16, ci), dtype=torch.float32, device="cuda")
+    K.wgrad([to_nhwc(dy, dtype)], srcs, dw, stride, [co], cins, msplit=msplit)
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy().reshape(co, 4, 4, ci).transpose(0, 3, 1, 2)
+    close(got, want, torch.float32, name)      # float32 accumulation of exact products in both modes
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", [("single", 2, [16], 4, 4, 8), ("cat", 2, [16, 32], 4, 4, 16),
+                                  ("co3", 2, [16, 16], 8, 8, 3), ("big", 2, [64, 64], 16, 16, 64)],
+                         ids=lambda c: c[0])
+def test_convT_wgrad(case, dtype, ws):
+    name, n, cins, h, w, co = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".tdw.x", (n, ci, h, w)), dtype)
+    wt = fill.uniform(name + ".tdw.w", (ci, co, 4, 4))
+    dy = rnd(fill.uniform(name + ".tdw.dy", (n, co, 2 * h, 2 * w)), dtype)
+    _, want, _ = ops.convT2d_bwd(x, wt, dy, need_dx=False)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    dw = torch.zeros((ci, 16, co), dtype=torch.float32, device="cuda")
+    K.wgrad(srcs, [to_nhwc(dy, dtype)], dw, 2, cins, [co])
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy().reshape(ci, 4, 4, co).transpose(0, 3, 1, 2)
+    close(got, want, torch.float32, name)
+
+
+# ---------------------------------------------------------------------------- BatchNorm, losses, Adam
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+def test_batchnorm_roundtrip(dtype, ws):
+    n, c, h, w = 3, 16, 9, 7
+    x = rnd(fill.uniform("gbn.x", (n, c, h, w), -2, 3), dtype)
+    g = fill.uniform("gbn.g", (c,), 0.5, 1.5)
+    b = fill.uniform("gbn.b", (c,), -0.5, 0.5)
+    rm0 = fill.uniform("gbn.rm", (c,))
+    rv0 = fill.uniform("gbn.rv", (c,), 0.5, 2.0)
+    y, cache, rm2, rv2, nbt2 = ops.bn_train_fwd(x, g, b, rm0, rv0, 5, repeats=2)
+    xt = to_nhwc(x, dtype)
+    rows = n * h * w
+    # statistics partials as a GEMM epilogue would write them: here 3 arbitrary row tiles
+    xf = torch.from_numpy(x.transpose(0, 2, 3, 1).reshape(rows, c)).cuda().double()
+    cuts = [0, 50, 120, rows]
+    psum = torch.stack([xf[a:e].sum(0) for a, e in zip(cuts[:-1], cuts[1:])]).float().contiguous()
+    psq = torch.stack([(xf[a:e] ** 2).sum(0) for a, e in zip(cuts[:-1], cuts[1:])]).float().contiguous()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gt, bt, rm, rv = dev(g), dev(b), dev(rm0), dev(rv0)
+    nbt = torch.tensor(5, dtype=torch.int64, device="cuda")
+    scale, shift, mean, invstd = (torch.empty(c, device="cuda") for _ in range(4))
+    K.bn_finalize(psum, psq, 3, c, rows, gt, bt, rm, rv, nbt, scale, shift, mean, invstd, repeats=2)
+    torch.cuda.synchronize()
+    close(rm.cpu().numpy(), rm2, torch.float32, "running_mean")
+    close(rv.cpu().numpy(), rv2, torch.float32, "running_var")
+    assert int(nbt) == nbt2 == 7
+    out_l = torch.empty_like(xt)
+    out_r = torch.empty_like(xt)
+    K.bn_act(xt, scale, shift, out_l, out_r)
+    close(from_nhwc(out_l, c), ops.leaky_relu(y), dtype, "bn+lrelu")
+    close(from_nhwc(out_r, c), ops.relu(y), dtype, "bn+relu")
+    # backward: dy = lrelu'(y) g1 + relu'(y) g2, then the BN backward
+    g1 = rnd(fill.uniform("gbn.g1", (n, c, h, w)), dtype)
+    g2 = rnd(fill.uniform("gbn.g2", (n, c, h, w)), dtype)
+    dy_ref = ops.leaky_relu_bwd(y, g1) + ops.relu_bwd(y, g2)
+    dx_ref, dg_ref, db_ref = ops.bn_train_bwd(rnd(dy_ref, dtype), g, cache)
+    dy = torch.empty_like(xt)
+    part, nt = K.bn_bwd_reduce(xt, scale, shift, mean, invstd, to_nhwc(g1, dtype), K.ACT_LRELU, to_nhwc(g2, dtype),
+                               K.ACT_RELU, dy, ws)
+    close(from_nhwc(dy, c), dy_ref, dtype, "dy")
+    dgamma, dbeta = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    coef = torch.empty(3 * c, device="cuda")
+    K.bn_bwd_finalize(part, nt, c, rows, gt, mean, invstd, dgamma, dbeta, coef)
+    dr = torch.empty_like(xt)
+    K.bn_bwd_apply(dy, xt, coef, dr)
+    torch.cuda.synchronize()
+    lo = torch.float32 if dtype == torch.float32 else torch.bfloat16
+    close(dgamma.cpu().numpy(), dg_ref, lo, "dgamma")
+    close(dbeta.cpu().numpy(), db_ref, lo, "dbeta")
+    close(from_nhwc(dr, c), dx_ref, dtype, "dx")
+    # eval-mode coefficients
+    K.bn_eval_coeffs(gt, bt, rm, rv, scale, shift)
+    K.bn_act(xt, scale, shift, out_l, None)
+    close(from_nhwc(out_l, c), ops.leaky_relu(ops.bn_eval_fwd(x, g, b, rm2, rv2)), dtype, "eval bn+lrelu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+def test_losses(dtype, ws):
+    x = rnd(fill.uniform("gl.x", (3, 1, 6, 5), -4, 4), dtype)
+    xt = to_nhwc(x, dtype)
+    acc = torch.zeros(1, device="cuda")
+    dl = torch.full_like(xt, 7.0)
+    K.bce_logits(xt, 1.0, 0.5, 0.5, acc, dl)
+    K.bce_logits(xt, 0.0, 0.5, 0.5, acc, None)
+    l1, g1 = ops.bce_logits(x, 1.0)
+    l0, _ = ops.bce_logits(x, 0.0)
+    torch.cuda.synchronize()
+    close(acc.cpu().numpy()[0], 0.5 * (l1 + l0), torch.float32, "bce loss")
+    close(from_nhwc(dl, 1), 0.5 * g1, dtype, "bce grad")
+    assert float(dl[..., 1:].float().abs().max()) == 0.0
+    f = rnd(np.tanh(fill.uniform("gl.f", (2, 3, 8, 8), -2, 2)), dtype)
+    r = rnd(fill.uniform("gl.r", (2, 3, 8, 8)), dtype)
+    cp = K.pad_ch(3, dtype)
+    dgan_full = rnd(fill.uniform("gl.dg", (2, 2 * cp, 8, 8), -1e-3, 1e-3), dtype)
+    acc.zero_()
+    dpre = torch.full((2, 8, 8, cp), 7.0, dtype=dtype, device="cuda")
+    K.l1_tanh_bwd(to_nhwc(f, dtype), to_nhwc(r, dtype), 3, to_nhwc(dgan_full, dtype), cp, 100.0, acc, dpre)
+    ll, gl = ops.l1_loss(f, r)
+    want = (dgan_full[:, cp:cp + 3] + 100.0 * gl) * (1 - f.astype(np.float64) ** 2)
+    torch.cuda.synchronize()
+    close(acc.cpu().numpy()[0], 100.0 * ll, torch.float32, "l1 loss")
+    close(from_nhwc(dpre, 3), want, dtype, "dpre")
+    cs = torch.zeros(cp, device="cuda")
+    K.colsum(dpre, cs, ws)
+    torch.cuda.synchronize()
+    close(cs.cpu().numpy()[:3], from_nhwc(dpre, 3).astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, "colsum")
+
+
+def test_adam():
+    n = 1003
+    p = fill.uniform("ga.p", (n,))
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    pt, mt, vt = (torch.from_numpy(a.copy()).cuda() for a in (np.pad(p, (0, 1)), np.pad(m, (0, 1)), np.pad(v, (0, 1))))
+    step_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for i in range(3):
+        g = fill.uniform(f"ga.g{i}", (n,), -1e-2, 1e-2)
+        p, m, v = ops.adam_step(p, g, m, v, i + 1)
+        gt = torch.from_numpy(np.pad(g, (0, 1))).cuda()
+        if i < 2:
+            K.adam(pt[:n], gt[:n], mt[:n], vt[:n], 1e-4, 0.5, 0.999, 1e-8, i + 1)
+        else:   # device-side step counter (hipGraph replay form)
+            step_dev.fill_(2)
+            K.adam_tick(step_dev)
+            K.adam(pt[:n], gt[:n], mt[:n], vt[:n], 1e-4, 0.5, 0.999, 1e-8, 0, step_dev=step_dev)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(pt[:n].cpu().numpy(), p, rtol=2e-6, atol=2e-7)
+    assert float(pt[n]) == 0.0
+
+
+def test_argument_errors_are_reported():
+    a = _lib.GatherArgs()
+    with pytest.raises(_lib.PfaError, match="struct_size"):
+        _lib.check(_lib.lib().pfa_gather_gemm(a, None), "pfa_gather_gemm")
+    with pytest.raises(_lib.PfaError, match="GPU tensors"):
+        K.pack_nhwc(torch.zeros(1, 3, 4, 4), torch.float32)
