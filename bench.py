@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GAN img-pairs/s of the complete Pix2Pix G+D training step (train_gan.py:52-71:
+G fwd, 3x D fwd, both backwards, both Adam updates) at 256x256x3, batch 16 per GPU, bf16 operands.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One JSON line on rank 0.  `value` = N * batch * K / (max over ranks of the timed K steps), inputs resident in
+HBM (a pool of pre-packed synthetic batches, seed 1234 + rank).  Extra objects:
+  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,128,128,2,2>): HIP-event
+                time of every launch of it over a pass of the same steps, against its algorithmic conv FLOPs
+                (2 * pixels * Cout * taps * Cin_real per launch; SURVEY 8d counts the same MACs)
+  cpu_baseline  the numpy oracle's gan_step (oracle/step.py, "port") on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "gan-aug-pfa_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_F32_TFLOPS = 157.3
+FLOP_PER_PAIR = {256: 86.79e9, 512: 351.38e9}      # minimal schedule, conv MACs x2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="img-pairs per GPU (BASELINE config 2: 16)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def kernel_roofline(trainer, xa, xb, steps, precision):
+    """HIP events (on torch's current stream = the stream every pfa kernel is launched on) around each
+    launch of the dominant implicit-GEMM instantiation, over `steps` eager steps of the same workload."""
+    from pfa_gan import kernels as K
+    real = K.gather_gemm
+    rec = []
+
+    def timed(mode, srcs, w, n, outs, grid, ws, **kw):
+        splitk = kw.get("splitk")
+        ctot = sum(s.shape[3] for s in srcs)
+        if splitk is None:
+            splitk = K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, ctot, srcs[0].dtype)
+        dominant = n > 64 and splitk == 1          # -> k_gather_gemm<T,128,128,2,2>, no split-K slab
+        if not dominant:
+            return real(mode, srcs, w, n, outs, grid, ws, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real(mode, srcs, w, n, outs, grid, ws, **kw)
+        e1.record()
+        taps = 4 if mode == K.TCONV_S2 else 16
+        classes = 4 if mode == K.TCONV_S2 else 1
+        rows = grid[0] * grid[1] * grid[2] * classes
+        rec.append((e0, e1, 2.0 * rows * n * taps * ctot))
+        return out
+
+    K.gather_gemm = timed
+    import pfa_gan.engine as E
+    E.K.gather_gemm = timed
+    try:
+        was_graph = trainer.use_graph
+        trainer.use_graph = False
+        for _ in range(steps):
+            trainer.step_packed(xa, xb)
+        torch.cuda.synchronize()
+        trainer.use_graph = was_graph
+    finally:
+        K.gather_gemm = real
+        E.K.gather_gemm = real
+    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+    flops = sum(f for _, _, f in rec)
+    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                traffic=None, kernel=f"k_gather_gemm<{precision},128,128,2,2>", launches_per_step=len(rec) // steps,
+                avg_launch_us=round(1e3 * ms / len(rec), 2), flop_per_launch=round(flops / len(rec)),
+                flop_share_of_step=round(flops / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3))
+
+
+def cpu_baseline(size, steps):
+    """The CPU restatement of the same step (oracle/step.py) on this host's cores: 1 warm-up + `steps` timed."""
+    import numpy as np
+    from oracle import fill, nets, step as ostep
+    b = 1
+    gst = fill.fill_state(nets.g_state_shapes(), seed=0, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(), seed=1, bn_noise=False)
+    go, do = ostep.new_adam_state(gst), ostep.new_adam_state(dst)
+    a = fill.uniform("cpu.a", (b, 3, size, size))
+    bb = fill.uniform("cpu.b", (b, 3, size, size))
+    ostep.gan_step(gst, dst, go, do, a, bb)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ostep.gan_step(gst, dst, go, do, a, bb)
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return dict(value=round(b * steps / dt, 4), unit="img-pairs/s", cores=cores, kind="port",
+                sample=f"oracle/step.py gan_step (numpy {np.__version__}, BLAS threads = cores), default nets, "
+                       f"{size}x{size}, batch {b}, {steps} steps after 1 warm-up, fp32")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} "
+                             f"bench.py ...` (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    import pfa_gan
+    from pfa_gan import _lib
+    _lib.lib()                                       # fail loudly if the HIP extension is missing
+    torch.manual_seed(0)                             # identical default init on every rank (reference init, a12)
+    gen = pfa_gan.UNetGenerator(3, 3).cuda()
+    disc = pfa_gan.NLayerDiscriminator(6).cuda()
+    trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph=not args.no_graph)
+    if world > 1:                                    # rank 0's parameters and buffers are the job's
+        for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
+            torch.distributed.broadcast(t, 0)
+        trainer.G.refresh_shadows(force=True)
+        trainer.Dn.refresh_shadows(force=True)
+
+    gsrc = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    pool = []
+    for _ in range(8):                               # distinct batches, already packed: resident in HBM
+        a = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
+        b = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
+        pool.append((trainer.pack(a), trainer.pack(b)))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    launches0 = _lib.launch_count()
+    for i in range(args.warmup):
+        trainer.step_packed(*pool[i % len(pool)])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step_packed(*pool[i % len(pool)])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax)
+    losses = trainer.losses.tolist()
+    assert all(l == l and abs(l) < 1e6 for l in losses), f"non-finite loss {losses}"
+    assert _lib.launch_count() > launches0
+
+    if rank == 0:
+        pairs = world * args.batch * args.steps
+        value = pairs / dt
+        flop_pair = FLOP_PER_PAIR.get(args.size)
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "GAN img-pairs/sec (G+D step, 256x256x3)" if args.size == 256 else f"GAN img-pairs/sec (G+D step, {args.size}x{args.size}x3)",
+            "value": round(value, 2), "unit": "img-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"{args.size}x{args.size} RGB Pix2Pix G+D step (UNetGenerator num_downs=7 ngf=64 + "
+                                   f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "launch": "eager" if args.no_graph else "hipGraph x3 segments",
+                       "last_losses": [round(l, 4) for l in losses]},
+        }
+        if flop_pair:
+            tf = value * flop_pair / 1e12 / world
+            out["step_mfma"] = {"algorithmic_tflops_per_gpu": round(tf, 2), "frac_of_peak": round(tf / peak, 4)}
+        if not args.no_roofline:
+            out["roofline"] = kernel_roofline(trainer, *pool[0], max(2, min(args.steps, 5)), args.precision)
+        if world == 1 and not args.no_cpu_baseline and args.size == 256:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

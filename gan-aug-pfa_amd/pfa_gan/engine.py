@@ -1,0 +1,448 @@
+"""Whole-network executors for UNetGenerator / NLayerDiscriminator on libpfa_hip.
+
+What the reference leaves to PyTorch's autograd and operator library (models.py:163-208,
+:246-247; train_gan.py:56-70) is scheduled here explicitly, layer by layer:
+
+  conv / convT  -> pfa_gather_gemm (MFMA implicit GEMM, BN statistics in its epilogue)
+  BatchNorm     -> pfa_bn_finalize + pfa_bn_act: the raw conv output is normalised once and
+                   written as the activated operand(s) its consumers read - LeakyReLU(y) for the next
+                   down-conv and ReLU(y) for the decoder (ReLU(LeakyReLU(y)) == ReLU(y));
+                   torch.cat of models.py:208 is never materialised (two source pointers)
+  backward      -> pfa_bn_bwd_* , pfa_wgrad, pfa_gather_gemm in dgrad geometry
+
+Activations are NHWC, bf16 or f32, channel-padded to 16 bytes.  Parameters live in one flat
+float32 arena per network (every nn.Parameter is a view into it, conv weights in channels-last
+memory = the kernels' [rows][16][c] layout); gradients accumulate into a matching arena.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from ._lib import PfaError
+
+
+# ------------------------------------------------------------------------------------ flat arenas
+class FlatParams:
+    """One float32 arena for all parameters of a module (+ a gradient arena of the same shape)."""
+
+    ALIGN = 4          # floats: every parameter starts on a 16-byte boundary (vector Adam)
+    registry = {}      # id(parameter) -> FlatParams, so an optimizer built from .parameters() finds its arena
+
+    def __init__(self, module):
+        params = [p for p in module.parameters()]
+        if not params:
+            raise PfaError("module has no parameters")
+        self.device = params[0].device
+        if self.device.type != "cuda":
+            raise PfaError("the HIP engine needs the module on a GPU (module.to('cuda'))")
+        self.slots = {}
+        off = 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise PfaError("master parameters must be float32")
+            self.slots[id(p)] = (off, p.numel())
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.params = params
+        with torch.no_grad():
+            for p in params:
+                o, n = self.slots[id(p)]
+                view = self._view(self.data, p, o, n)
+                view.copy_(p.data)
+                p.data = view
+        self.attach_grads()
+        for p in params:
+            FlatParams.registry[id(p)] = self
+
+    @staticmethod
+    def _view(arena, p, o, n):
+        seg = arena[o:o + n]
+        if p.dim() == 4:      # [R, C, 4, 4] logical, [R][4][4][C] in memory (channels last)
+            r, c = p.shape[0], p.shape[1]
+            return seg.view(r, 4, 4, c).permute(0, 3, 1, 2)
+        return seg.view(p.shape)
+
+    def attach_grads(self):
+        """Point every p.grad at its slice of the gradient arena (after zero_grad(set_to_none=True))."""
+        for p in self.params:
+            o, n = self.slots[id(p)]
+            p.grad = self._view(self.grad, p, o, n)
+
+    def seg(self, arena, p):
+        o, n = self.slots[id(p)]
+        return arena[o:o + n]
+
+    def bound(self):
+        p = self.params[0]
+        o, _ = self.slots[id(p)]
+        return p.data.data_ptr() == self.data.data_ptr() + 4 * o
+
+
+def flat_of(module):
+    flat = getattr(module, "_pfa_flat", None)
+    if flat is None or not flat.bound():
+        flat = FlatParams(module)
+        object.__setattr__(module, "_pfa_flat", flat)
+    return flat
+
+
+class Ctx:
+    """Named, shape-stable device buffers of one forward/backward pass (allocated once, reused every step)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._t = {}
+        self.v = {}
+
+    def buf(self, name, shape, dtype):
+        t = self._t.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self._t[name] = t
+        return t
+
+
+# ------------------------------------------------------------------------------------ one conv layer
+class Layer:
+    """A Conv2d or ConvTranspose2d with its optional BatchNorm2d, plus the kernel-side weight shadows."""
+
+    def __init__(self, flat, dtype, conv, norm, in_parts, name):
+        self.name = name
+        self.flat, self.dtype = flat, dtype
+        self.conv, self.w, self.b = conv, conv.weight, conv.bias
+        self.transposed = isinstance(conv, nn.ConvTranspose2d)
+        self.stride = conv.stride[0]
+        if conv.kernel_size != (4, 4) or conv.padding != (1, 1) or self.stride not in (1, 2):
+            raise PfaError(f"{name}: only 4x4 / padding 1 / stride 1|2 convolutions are built")
+        if norm is not None and not isinstance(norm, nn.BatchNorm2d):
+            raise NotImplementedError(f"{name}: the HIP engine implements nn.BatchNorm2d (the reference's default, "
+                                      f"train_gan.py:138-139); {type(norm).__name__} runs on the CPU path only")
+        self.bn = norm
+        self.cout = conv.out_channels
+        self.cout_p = K.pad_ch(self.cout, dtype)
+        self.in_real = list(in_parts)
+        self.in_pad = [K.pad_ch(c, dtype) for c in in_parts]
+        if sum(in_parts) != conv.in_channels:
+            raise PfaError(f"{name}: input split {in_parts} != in_channels {conv.in_channels}")
+        dev = flat.device
+        if self.transposed:
+            # master [Ci][16][Co]: rows are the (unpadded) concat of the inputs
+            if self.in_real != self.in_pad:
+                raise PfaError(f"{name}: transposed-conv input channels {in_parts} must be multiples of "
+                               f"{K.ch_of(dtype)} in {dtype} mode")
+            self.rows, self.cparts = conv.in_channels, [(self.cout, self.cout_p)]
+        else:
+            self.rows, self.cparts = self.cout, list(zip(self.in_real, self.in_pad))
+        if self.bn is not None and self.cout != self.cout_p:
+            raise PfaError(f"{name}: BatchNorm layers need out_channels % {K.ch_of(dtype)} == 0 in {dtype} mode")
+        cp = sum(p for _, p in self.cparts)
+        self.rows_p = K.pad_ch(self.rows, dtype)
+        self.same = torch.zeros((self.rows, 16, cp), dtype=dtype, device=dev)
+        self.tr = torch.zeros((cp, 16, self.rows_p), dtype=dtype, device=dev)
+
+    # kernel operands -------------------------------------------------------------
+    @property
+    def w_fwd(self):
+        return self.tr if self.transposed else self.same
+
+    @property
+    def w_bwd(self):
+        return self.same if self.transposed else self.tr
+
+    def refresh(self):
+        (c1r, c1p), (c2r, c2p) = self.cparts[0], (self.cparts[1] if len(self.cparts) > 1 else (0, 0))
+        K.weight_shadow(self.flat.seg(self.flat.data, self.w), self.rows, c1r, c1p, c2r, c2p, self.rows_p,
+                        self.same, self.tr)
+
+    def dw(self, garena):
+        return self.flat.seg(garena, self.w)
+
+    def db(self, garena):
+        return self.flat.seg(garena, self.b)
+
+
+class _Engine:
+    def __init__(self, module, dtype):
+        self.module, self.dtype = module, dtype
+        self.flat = flat_of(module)
+        self.device = self.flat.device
+        self.ws = K.Workspace(self.device)
+        self.layers = []
+        self._versions = None
+        self._scratch = None
+
+    def still_bound(self):
+        return self.flat.bound() and getattr(self.module, "_pfa_flat", None) is self.flat
+
+    def new_ctx(self):
+        return Ctx(self.device)
+
+    def scratch_ctx(self):
+        if self._scratch is None:
+            self._scratch = self.new_ctx()
+        return self._scratch
+
+    def refresh_shadows(self, force=False):
+        """Re-emit the kernel-side weight copies when a master parameter changed (torch bumps
+        Tensor._version on every in-place write; the fused trainer forces it after its own Adam)."""
+        versions = tuple(L.w._version for L in self.layers)
+        if force or versions != self._versions:
+            for L in self.layers:
+                L.refresh()
+            self._versions = versions
+
+    # BatchNorm plumbing ------------------------------------------------------------
+    def _bn_coeffs(self, L, ctx, tag, st, count, train, repeats):
+        c = L.cout
+        f32 = torch.float32
+        scale, shift = ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32)
+        bn = L.bn
+        if train:
+            psum, psq, nt = st
+            mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
+            track = bn.track_running_stats and bn.running_mean is not None
+            K.bn_finalize(psum, psq, nt, c, count, bn.weight, bn.bias, bn.running_mean if track else None,
+                          bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                          scale, shift, mean, invstd, repeats=repeats if track else 0)
+        else:
+            K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, scale, shift)
+        return scale, shift
+
+    def _bn_backward(self, L, ctx, tag, raw, count, garena, g1, act1, g2=None, act2=K.ACT_NONE, param_grads=True):
+        f32 = torch.float32
+        c = L.cout
+        dy = ctx.buf(tag + ".dy", raw.shape, raw.dtype)
+        scale, shift = ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32)
+        mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
+        part, nt = K.bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, self.ws)
+        coef = ctx.buf(tag + ".coef", (3 * c,), f32)
+        dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
+        dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
+        K.bn_bwd_finalize(part, nt, c, count, L.bn.weight, mean, invstd, dgamma, dbeta, coef)
+        K.bn_bwd_apply(dy, raw, coef, dy)
+        return dy
+
+    def _act_backward(self, ctx, tag, act_out, g1, act1, g2=None, act2=K.ACT_NONE):
+        """Conv output without a norm: its gradient is act'(.)*g, and sign(act_out) == sign(pre-activation)."""
+        dr = ctx.buf(tag + ".dy", act_out.shape, act_out.dtype)
+        K.bn_bwd_reduce(act_out, None, None, None, None, g1, act1, g2, act2, dr, self.ws)
+        return dr
+
+
+# ------------------------------------------------------------------------------------ generator
+class GeneratorEngine(_Engine):
+    """UNetGenerator.forward / backward (models.py:163-208) on the HIP kernels."""
+
+    def __init__(self, gen, dtype):
+        super().__init__(gen, dtype)
+        if getattr(gen, "_use_dropout", False):
+            raise NotImplementedError("use_dropout=True is not built into the HIP engine (the reference's "
+                                      "train_gan.py constructs the generator without it)")
+        blocks = gen.blocks()
+        self.D = len(blocks)
+        self.down, self.up = [], []
+        enc = [b._parts["down"].out_channels for b in blocks]
+        for k, b in enumerate(blocks):
+            pr = b._parts
+            cin = [pr["down"].in_channels]
+            self.down.append(Layer(self.flat, dtype, pr["down"], pr["down_norm"], cin, f"e{k + 1}"))
+            up_in = [enc[k]] if k == self.D - 1 else [enc[k], blocks[k + 1]._parts["up"].out_channels]
+            self.up.append(Layer(self.flat, dtype, pr["up"], pr["up_norm"], up_in, f"d{k + 1}"))
+        for k in range(1, self.D - 1):
+            if self.down[k].bn is None:
+                raise PfaError("unexpected generator structure: middle level without a norm layer")
+        self.layers = self.down + self.up
+        self.out_nc = self.up[0].cout
+
+    def forward(self, x, ctx, train=True, bn_repeats=1):
+        """x: NHWC [B,H,W,cp_in].  Returns tanh output NHWC [B,H,W,cp_out] (pad channels zero)."""
+        D, dt = self.D, self.dtype
+        B, H, W, _ = x.shape
+        if H % (1 << D) or W % (1 << D):
+            raise PfaError(f"input {H}x{W} must be a multiple of 2^num_downs = {1 << D}")
+        ctx.v.update(x=x, aL={}, aR={}, uR={}, train=train)
+        a = x
+        for k in range(D):
+            L = self.down[k]
+            h, w = H >> (k + 1), W >> (k + 1)
+            shape = (B, h, w, L.cout_p)
+            if k == D - 1:          # bottom of the U: no norm, consumed through ReLU only
+                aR = ctx.buf(f"e{k}.aR", shape, dt)
+                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aR], (B, h, w), self.ws, act=K.ACT_RELU)
+                ctx.v["aR"][k] = aR
+                break
+            raw = ctx.buf(f"e{k}.raw", shape, dt)
+            aL, aR = ctx.buf(f"e{k}.aL", shape, dt), ctx.buf(f"e{k}.aR", shape, dt)
+            if L.bn is None:        # outermost: no norm
+                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws)
+                K.bn_act(raw, None, None, aL, aR)
+            else:
+                st = K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
+                scale, shift = self._bn_coeffs(L, ctx, f"e{k}", st, B * h * w, train, bn_repeats)
+                K.bn_act(raw, scale, shift, aL, aR)
+            ctx.v["aL"][k], ctx.v["aR"][k] = aL, aR
+            a = aL
+        for k in range(D - 1, 0, -1):
+            L = self.up[k]
+            h, w = H >> (k + 1), W >> (k + 1)
+            srcs = [ctx.v["aR"][k]] if k == D - 1 else [ctx.v["aR"][k], ctx.v["uR"][k + 1]]
+            raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
+            st = K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
+            scale, shift = self._bn_coeffs(L, ctx, f"u{k}", st, B * 4 * h * w, train, bn_repeats)
+            uR = ctx.buf(f"u{k}.uR", raw.shape, dt)
+            K.bn_act(raw, scale, shift, None, uR)
+            ctx.v["uR"][k] = uR
+        L = self.up[0]
+        fake = ctx.buf("fake", (B, H, W, L.cout_p), dt)
+        K.gather_gemm(K.TCONV_S2, [ctx.v["aR"][0], ctx.v["uR"][1]], L.w_fwd, L.cout, [fake], (B, H // 2, W // 2),
+                      self.ws, bias=L.b, act=K.ACT_TANH)
+        ctx.v["fake"] = fake
+        return fake
+
+    def backward(self, ctx, dpre, garena):
+        """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena."""
+        if not ctx.v.get("train", False):
+            raise PfaError("generator backward needs a training-mode forward")
+        D, dt = self.D, self.dtype
+        v = ctx.v
+        B, H, W, _ = v["x"].shape
+        g_skip, g_up = {}, {}
+        # ---- decoder, outermost first
+        d = dpre
+        for k in range(D):
+            L = self.up[k]
+            h, w = H >> (k + 1), W >> (k + 1)            # input grid of this transposed conv
+            if k > 0:
+                raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
+                d = self._bn_backward(L, ctx, f"u{k}", raw, B * 4 * h * w, garena, g_up[k], K.ACT_RELU)
+            srcs = [v["aR"][k]] if k == D - 1 else [v["aR"][k], v["uR"][k + 1]]
+            K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout])
+            if L.b is not None:
+                K.colsum(d, L.db(garena), self.ws, c_out=L.cout)
+            g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
+            outs = [g_skip[k]]
+            if k < D - 1:
+                g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
+                outs.append(g_up[k + 1])
+            K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, outs, (B, h, w), self.ws)
+        # ---- encoder, innermost first
+        g_down = None
+        for k in range(D - 1, -1, -1):
+            L = self.down[k]
+            h, w = H >> (k + 1), W >> (k + 1)
+            if k == D - 1:
+                dr = self._act_backward(ctx, f"e{k}", v["aR"][k], g_skip[k], K.ACT_RELU)
+            elif L.bn is None:
+                dr = self._act_backward(ctx, f"e{k}", v["aL"][k], g_down, K.ACT_LRELU, g_skip[k], K.ACT_RELU)
+            else:
+                raw = ctx.buf(f"e{k}.raw", (B, h, w, L.cout_p), dt)
+                dr = self._bn_backward(L, ctx, f"e{k}", raw, B * h * w, garena, g_down, K.ACT_LRELU, g_skip[k],
+                                       K.ACT_RELU)
+            src = v["x"] if k == 0 else v["aL"][k - 1]
+            K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real)
+            if L.b is not None:
+                K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
+            if k > 0:
+                g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
+                K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
+
+
+# ------------------------------------------------------------------------------------ discriminator
+class DiscriminatorEngine(_Engine):
+    """NLayerDiscriminator.forward / backward (models.py:246-247).
+
+    in_split: how the caller hands over the input channels, e.g. (3, 3) for (real_A, B) as two tensors -
+    torch.cat((real_A, x), 1) of train_gan.py:57,59,66 then never happens; None = one tensor.
+    """
+
+    def __init__(self, disc, dtype, in_split=None):
+        super().__init__(disc, dtype)
+        convs, norms = [], []
+        mods = list(disc.model)
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.Conv2d):
+                convs.append(m)
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                norms.append(nxt if nxt is not None and not isinstance(nxt, (nn.LeakyReLU, nn.Conv2d)) else None)
+        in_parts = list(in_split) if in_split else [convs[0].in_channels]
+        self.in_parts = in_parts
+        self.layers = []
+        for i, (c, nm) in enumerate(zip(convs, norms)):
+            parts = in_parts if i == 0 else [c.in_channels]
+            self.layers.append(Layer(self.flat, dtype, c, nm, parts, f"c{i + 1}"))
+        if self.layers[0].bn is not None or self.layers[-1].bn is not None:
+            raise PfaError("unexpected discriminator structure")
+
+    @staticmethod
+    def _out_hw(L, h, w):
+        return (h // 2, w // 2) if L.stride == 2 else (h - 1, w - 1)
+
+    def forward(self, srcs, ctx, train=True):
+        """srcs: list of NHWC tensors matching in_split.  Returns logits NHWC [B,ho,wo,cp(1)]."""
+        dt = self.dtype
+        B, H, W, _ = srcs[0].shape
+        ctx.v.update(srcs=list(srcs), a={}, train=train)
+        a, h, w = list(srcs), H, W
+        n = len(self.layers)
+        for i, L in enumerate(self.layers):
+            if L.stride == 2 and (h % 2 or w % 2):
+                raise PfaError(f"{L.name}: stride-2 conv needs an even input, got {h}x{w}")
+            ho, wo = self._out_hw(L, h, w)
+            if ho < 1 or wo < 1:
+                raise PfaError("input too small for this discriminator")
+            mode = K.CONV_S2 if L.stride == 2 else K.CONV_S1
+            shape = (B, ho, wo, L.cout_p)
+            if L.bn is None:
+                out = ctx.buf(f"c{i}.a", shape, dt)
+                K.gather_gemm(mode, a, L.w_fwd, L.cout, [out], (B, ho, wo), self.ws, bias=L.b,
+                              act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE)
+            else:
+                raw = ctx.buf(f"c{i}.raw", shape, dt)
+                st = K.gather_gemm(mode, a, L.w_fwd, L.cout, [raw], (B, ho, wo), self.ws, bias=L.b, stats=train)
+                scale, shift = self._bn_coeffs(L, ctx, f"c{i}", st, B * ho * wo, train, 1)
+                out = ctx.buf(f"c{i}.a", shape, dt)
+                K.bn_act(raw, scale, shift, out, None)
+            ctx.v["a"][i] = out
+            a, h, w = [out], ho, wo
+        return a[0]
+
+    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False):
+        """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
+        computes and discards D's weight gradients there, train_gan.py:70 then :55)."""
+        if not ctx.v.get("train", False):
+            raise PfaError("discriminator backward needs a training-mode forward")
+        dt = self.dtype
+        v = ctx.v
+        n = len(self.layers)
+        g = dlogits
+        dx = None
+        for i in range(n - 1, -1, -1):
+            L = self.layers[i]
+            out = v["a"][i]
+            B, ho, wo, _ = out.shape
+            if i == n - 1:
+                dr = g
+            elif L.bn is None:
+                dr = self._act_backward(ctx, f"c{i}", out, g, K.ACT_LRELU)
+            else:
+                raw = ctx.buf(f"c{i}.raw", out.shape, dt)
+                dr = self._bn_backward(L, ctx, f"c{i}", raw, B * ho * wo, garena, g, K.ACT_LRELU,
+                                       param_grads=param_grads)
+            inputs = v["srcs"] if i == 0 else [v["a"][i - 1]]
+            if param_grads:
+                K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real)
+                if L.b is not None:
+                    K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
+            if i > 0 or need_dx:
+                hin, win = inputs[0].shape[1:3]
+                cp = sum(L.in_pad)
+                g = ctx.buf(f"g.c{i}", (B, hin, win, cp), dt)
+                if L.stride == 2:
+                    K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, cp, [g], (B, ho, wo), self.ws)
+                else:
+                    K.gather_gemm(K.CONV_S1_DGRAD, [dr], L.w_bwd, cp, [g], (B, hin, win), self.ws)
+                if i == 0:
+                    dx = g
+        return dx

@@ -33,6 +33,16 @@ _DTYPES = {"fp32": torch.float32, "f32": torch.float32, "float32": torch.float32
            "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
 
 
+def _contiguous_state_dict(module, state_dict, prefix, local_metadata):
+    """Checkpoints keep the reference layout (train_gan.py:149-153): plain NCHW-contiguous float32 tensors with
+    their own storage, whatever memory layout the engine keeps the live parameters in."""
+    for k, v in list(state_dict.items()):
+        if k.startswith(prefix) and isinstance(v, torch.Tensor) and v.dim() > 0:
+            if not v.is_contiguous() or v.untyped_storage().nbytes() != v.numel() * v.element_size():
+                state_dict[k] = v.detach().clone(memory_format=torch.contiguous_format)
+    return state_dict
+
+
 def resolve_dtype(precision):
     if isinstance(precision, torch.dtype):
         return precision
@@ -106,6 +116,7 @@ class UNetGenerator(nn.Module):
         self._use_dropout = use_dropout
         self.precision = default_precision()
         object.__setattr__(self, "_engines", {})
+        self._register_state_dict_hook(_contiguous_state_dict)
 
     def blocks(self):
         """Levels outermost -> innermost."""
@@ -153,6 +164,7 @@ class NLayerDiscriminator(nn.Module):
         self._norm_layer = norm_layer
         self.precision = default_precision()
         object.__setattr__(self, "_engines", {})
+        self._register_state_dict_hook(_contiguous_state_dict)
 
     def set_precision(self, precision):
         self.precision = precision

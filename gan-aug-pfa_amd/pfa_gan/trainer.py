@@ -1,0 +1,301 @@
+"""The fused Pix2Pix training step: train_gan.train_gan_one_epoch (train_gan.py:46-75) on the HIP engines.
+
+Schedule per batch - the minimal one that reproduces the reference's results:
+  D phase  G fwd x1 (BN buffers take the update twice: the reference runs G twice on unchanged weights,
+           train_gan.py:56,65) -> D(real) -> D(fake) -> BCE -> D backward x2 -> Adam(D)
+  G phase  D(fake) with the updated D -> BCE + 100*L1 -> D input-gradient only -> G backward -> Adam(G)
+No torch.cat, no .item() sync inside the step; losses stay on the device until asked for.
+"""
+import math
+
+import torch
+
+from . import kernels as K
+from ._lib import PfaError
+from .engine import FlatParams
+from .models import resolve_dtype
+
+LAMBDA_L1 = 100.0      # train_gan.py:33
+LEARNING_RATE = 1e-4   # train_gan.py:28-29
+BETAS = (0.5, 0.999)   # train_gan.py:30,140-141
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """optim.Adam(lr, betas) semantics (weight_decay 0, amsgrad off) as one pfa_adam launch per network.
+
+    Takes `model.parameters()` like torch.optim.Adam (train_gan.py:140-141); the parameters must belong to
+    one module, whose flat arena (pfa_gan.engine.FlatParams) holds p, and m / v live in matching arenas.
+    """
+
+    def __init__(self, params, lr=LEARNING_RATE, betas=BETAS, eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) != 1:
+            raise PfaError("FusedAdam supports a single parameter group")
+        self._flat = None
+        self.m = self.v = None
+        self.steps = 0
+        self.step_dev = None
+
+    def flat(self):
+        if self._flat is None or not self._flat.bound():
+            ps = self.param_groups[0]["params"]
+            flats = {id(FlatParams.registry.get(id(p))) for p in ps}
+            flat = FlatParams.registry.get(id(ps[0]))
+            if flat is None or len(flats) != 1 or len(ps) != len(flat.params):
+                raise PfaError("FusedAdam needs all parameters of ONE model that is already on the GPU "
+                               "(build it with model.parameters() after model.to('cuda'); the arena is created by "
+                               "model.engine())")
+            if self._flat is not None and self.m is not None and self.m.numel() == flat.total:
+                pass                      # model re-bound (e.g. after load): keep the moments
+            else:
+                self.m = torch.zeros_like(flat.data)
+                self.v = torch.zeros_like(flat.data)
+                self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
+            self._flat = flat
+        return self._flat
+
+    def zero_grad(self, set_to_none=False):
+        K.fill_zero(self.flat().grad)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, graph_safe=False):
+        flat = self.flat()
+        g = self.param_groups[0]
+        self.steps += 1
+        if graph_safe:      # step count read from device memory so that a captured launch stays valid on replay
+            K.adam_tick(self.step_dev)
+            K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0,
+                   step_dev=self.step_dev, grad_scale=grad_scale)
+        else:
+            K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.steps,
+                   grad_scale=grad_scale)
+
+    def state_dict(self):
+        self.flat()
+        return dict(steps=self.steps, m=self.m.clone(), v=self.v.clone(), param_groups=[
+            {k: v for k, v in self.param_groups[0].items() if k != "params"}])
+
+    def load_state_dict(self, sd):
+        self.flat()
+        self.steps = int(sd["steps"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.step_dev.fill_(self.steps)
+        self.param_groups[0].update(sd["param_groups"][0])
+
+
+class GanTrainer:
+    """Owns the engines, contexts and optimizers of one (generator, discriminator) pair on one GPU."""
+
+    def __init__(self, gen, disc, opt_g=None, opt_d=None, precision="bf16", lambda_l1=LAMBDA_L1, process_group=None,
+                 use_graph=False):
+        self.gen, self.disc = gen, disc
+        self.dtype = resolve_dtype(precision)
+        nc_a = gen.input_nc
+        nc_b = disc.input_nc - nc_a
+        if nc_b != gen.output_nc:
+            raise PfaError("discriminator input_nc must equal generator input_nc + output_nc (train_gan.py:139)")
+        self.G = gen.engine(self.dtype)
+        self.Dn = disc.engine(self.dtype, in_split=(nc_a, nc_b))
+        self.opt_g = opt_g if opt_g is not None else FusedAdam(gen.parameters())
+        self.opt_d = opt_d if opt_d is not None else FusedAdam(disc.parameters())
+        for o in (self.opt_g, self.opt_d):
+            if not isinstance(o, FusedAdam):
+                raise PfaError("GanTrainer drives pfa_gan.FusedAdam optimizers (same hyper-parameters as optim.Adam)")
+        self.opt_g.flat(), self.opt_d.flat()
+        self.lambda_l1 = float(lambda_l1)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        dev = self.G.device
+        self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
+        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)     # [loss_d, loss_g] of the last step
+        self.loss_sums = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.nsteps = 0
+        self.use_graph = use_graph
+        self._graphs = None
+        self._static = None
+        self.G.refresh_shadows(force=True)
+        self.Dn.refresh_shadows(force=True)
+
+    # ----------------------------------------------------------------------------------- pieces of a step
+    def _d_phase(self, xa, xb, graph_safe):
+        G, Dn = self.G, self.Dn
+        K.fill_zero(self.losses)
+        self.opt_d.zero_grad()
+        fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
+        lr = Dn.forward([xa, xb], self.ctx_r, train=True)
+        dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
+        K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+        lf = Dn.forward([xa, fake], self.ctx_f, train=True)
+        dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
+        K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
+        garena = self.opt_d.flat().grad
+        Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
+        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
+
+    def _d_update_g_phase(self, xa, xb, graph_safe):
+        G, Dn = self.G, self.Dn
+        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
+        Dn.refresh_shadows(force=True)
+        self.opt_g.zero_grad()
+        fake = self.gctx.v["fake"]
+        lg = Dn.forward([xa, fake], self.ctx_r, train=True)
+        dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
+        K.bce_logits(lg, 1.0, 1.0, 1.0, self.losses[1:2], dl_g)
+        dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True)
+        dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
+        K.l1_tanh_bwd(fake, xb, G.out_nc, dx, xa.shape[3], self.lambda_l1, self.losses[1:2], dpre)
+        G.backward(self.gctx, dpre, self.opt_g.flat().grad)
+
+    def _g_update(self, graph_safe):
+        self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
+        self.G.refresh_shadows(force=True)
+        self.loss_sums += self.losses
+
+    def _allreduce(self, opt):
+        if self.world > 1:
+            torch.distributed.all_reduce(opt.flat().grad, group=self.pg)
+
+    # ----------------------------------------------------------------------------------- public API
+    def pack(self, x):
+        """NCHW float32 batch (what batch["image1"].to(DEVICE) is, train_gan.py:53-54) -> engine layout."""
+        return K.pack_nhwc(x, self.dtype)
+
+    def step_packed(self, xa, xb):
+        """One G+D step on already packed NHWC inputs.  Returns the device tensor [loss_d, loss_g]."""
+        if self.use_graph:
+            return self._step_graph(xa, xb)
+        self._d_phase(xa, xb, False)
+        self._allreduce(self.opt_d)
+        self._d_update_g_phase(xa, xb, False)
+        self._allreduce(self.opt_g)
+        self._g_update(False)
+        self.nsteps += 1
+        return self.losses
+
+    def step(self, real_a, real_b):
+        return self.step_packed(self.pack(real_a), self.pack(real_b))
+
+    def _step_graph(self, xa, xb):
+        """The same three segments captured once as hipGraphs (static shapes and addresses); the gradient
+        all-reduces stay ordinary RCCL calls between them."""
+        if self._graphs is None:
+            self._static = (torch.empty_like(xa), torch.empty_like(xb))
+            sa, sb = self._static
+            sa.copy_(xa)
+            sb.copy_(xb)
+            # warm-up outside capture: allocates every context buffer and workspace
+            state = self._snapshot()
+            for _ in range(2):
+                self._d_phase(sa, sb, True)
+                self._d_update_g_phase(sa, sb, True)
+                self._g_update(True)
+            self._restore(state)
+            torch.cuda.synchronize()
+            segs = []
+            for fn in (lambda: self._d_phase(sa, sb, True), lambda: self._d_update_g_phase(sa, sb, True),
+                       lambda: self._g_update(True)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fn()
+                segs.append(g)
+            self._restore(state)
+            self._graphs = segs
+        sa, sb = self._static
+        sa.copy_(xa)
+        sb.copy_(xb)
+        self._graphs[0].replay()
+        self._allreduce(self.opt_d)
+        self._graphs[1].replay()
+        self._allreduce(self.opt_g)
+        self._graphs[2].replay()
+        self.opt_g.steps += 1
+        self.opt_d.steps += 1
+        self.nsteps += 1
+        return self.losses
+
+    def _snapshot(self):
+        bufs = [b for m in (self.gen, self.disc) for b in m.buffers()]
+        return dict(g=self.opt_g.flat().data.clone(), d=self.opt_d.flat().data.clone(),
+                    gm=self.opt_g.m.clone(), gv=self.opt_g.v.clone(), dm=self.opt_d.m.clone(), dv=self.opt_d.v.clone(),
+                    gs=(self.opt_g.steps, self.opt_g.step_dev.clone()), ds=(self.opt_d.steps, self.opt_d.step_dev.clone()),
+                    bufs=[b.clone() for b in bufs], sums=self.loss_sums.clone())
+
+    def _restore(self, st):
+        self.opt_g.flat().data.copy_(st["g"]); self.opt_d.flat().data.copy_(st["d"])
+        self.opt_g.m.copy_(st["gm"]); self.opt_g.v.copy_(st["gv"])
+        self.opt_d.m.copy_(st["dm"]); self.opt_d.v.copy_(st["dv"])
+        self.opt_g.steps = st["gs"][0]; self.opt_g.step_dev.copy_(st["gs"][1])
+        self.opt_d.steps = st["ds"][0]; self.opt_d.step_dev.copy_(st["ds"][1])
+        bufs = [b for m in (self.gen, self.disc) for b in m.buffers()]
+        for b, s in zip(bufs, st["bufs"]):
+            b.copy_(s)
+        self.loss_sums.copy_(st["sums"])
+        self.G.refresh_shadows(force=True)
+        self.Dn.refresh_shadows(force=True)
+
+    def epoch_losses(self, reset=True):
+        """(mean loss_d, mean loss_g) since the last reset: ONE device->host sync, not four per step."""
+        n = max(self.nsteps, 1)
+        ld, lg = (self.loss_sums / n).tolist()
+        if reset:
+            self.loss_sums.zero_()
+            self.nsteps = 0
+        return ld, lg
+
+
+def _trainer_for(gen, disc, opt_g, opt_d, precision=None):
+    tr = getattr(gen, "_pfa_trainer", None)
+    if tr is None or tr.disc is not disc or tr.opt_g is not opt_g or tr.opt_d is not opt_d \
+            or not (tr.G.still_bound() and tr.Dn.still_bound()):
+        tr = GanTrainer(gen, disc, opt_g, opt_d, precision=precision or gen.precision)
+        object.__setattr__(gen, "_pfa_trainer", tr)
+    return tr
+
+
+def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=LAMBDA_L1):
+    """Same contract as the reference's train_gan_one_epoch (train_gan.py:46-75): iterates `loader` (dict
+    batches with "image1"/"image2"), returns (mean loss_d, mean loss_g).
+
+    GPU model + FusedAdam optimizers -> the fused HIP step.  Anything else (CPU model, torch.optim.Adam)
+    -> the reference's own sequence of module calls, where a GPU model still runs every forward/backward
+    on the HIP engines through autograd.
+    """
+    gen.train()
+    disc.train()
+    p = next(gen.parameters())
+    device = p.device if device is None else device
+    if p.is_cuda and isinstance(opt_g, FusedAdam) and isinstance(opt_d, FusedAdam):
+        tr = _trainer_for(gen, disc, opt_g, opt_d)
+        tr.lambda_l1 = float(lambda_l1)
+        tr.epoch_losses(reset=True)
+        for batch in loader:
+            if batch is None:
+                continue
+            tr.step(batch["image1"].to(device, non_blocking=True), batch["image2"].to(device, non_blocking=True))
+        return tr.epoch_losses()
+    bce = torch.nn.BCEWithLogitsLoss()
+    l1 = torch.nn.L1Loss()
+    sum_d = sum_g = 0.0
+    n = 0
+    for batch in loader:
+        if batch is None:
+            continue
+        real_a, real_b = batch["image1"].to(device), batch["image2"].to(device)
+        opt_d.zero_grad()
+        fake = gen(real_a).detach()
+        pr = disc(torch.cat((real_a, real_b), 1))
+        pf = disc(torch.cat((real_a, fake), 1))
+        loss_d = (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf))) * 0.5
+        loss_d.backward()
+        opt_d.step()
+        opt_g.zero_grad()
+        fake = gen(real_a)
+        pg = disc(torch.cat((real_a, fake), 1))
+        loss_g = bce(pg, torch.ones_like(pg)) + l1(fake, real_b) * lambda_l1
+        loss_g.backward()
+        opt_g.step()
+        sum_d += loss_d.item()
+        sum_g += loss_g.item()
+        n += 1
+    return sum_d / max(n, 1), sum_g / max(n, 1)

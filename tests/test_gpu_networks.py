@@ -1,0 +1,256 @@
+"""-m gpu: whole-network and whole-step parity of the HIP engines against reference outputs (tests/golden)
+and the numpy oracle.  fp32 mode carries the north-star gate: 1e-3 abs / 1e-2 rel on the forward."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+import pfa_gan
+from conftest import assert_close
+from make_golden import NET_CASES, STEP_CASES
+from oracle import fill, nets, step as ostep
+from pfa_gan import _lib
+
+pytestmark = pytest.mark.gpu
+
+ABS, REL = 1e-3, 1e-2          # the north star's forward gate
+
+
+def load(module, st):
+    module.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in st.items()}, strict=True)
+
+
+def grad_close(got, want, what, rel_l2=2e-3):
+    """Gradient parity that tolerates the rare ReLU knife-edge element (tests/make_golden.py:_pick_seed)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-12)
+    err = np.abs(got - want) / scale
+    l2 = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-12)
+    assert np.median(err) < 2e-4 and l2 < rel_l2, f"{what}: rel L2 {l2:.2e}, median {np.median(err):.2e}, max {err.max():.2e}"
+
+
+@pytest.mark.parametrize("case", NET_CASES, ids=[c[0] for c in NET_CASES])
+def test_generator_fp32_vs_reference(golden, case):
+    name, nd, ngf, ndf, n, h = case
+    z = golden("nets")
+    gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=1)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    load(G, gst)
+    seed = int(z[f"{name}.g.seed"])
+    x = torch.from_numpy(fill.uniform(f"{name}.x", (n, 3, h, h), seed=seed)).cuda()
+    G.train()
+    before = _lib.launch_count()
+    y = G(x)
+    assert _lib.launch_count() - before > 20, "forward must run on libpfa_hip kernels"
+    assert_close(y.detach().cpu().numpy(), z[f"{name}.g.y"], ABS, REL, "G train forward")
+    dy = torch.from_numpy(fill.uniform(f"{name}.g.dy", tuple(y.shape), seed=seed)).cuda()
+    for p in G.parameters():
+        p.grad = None
+    y.backward(dy)
+    for k, p in G.named_parameters():
+        grad_close(fill.compact(p.grad.cpu().numpy()), z[f"{name}.g.grad.{k}"], f"G grad {k}")
+    for k, b in G.named_buffers():
+        assert_close(b.cpu().numpy(), z[f"{name}.g.buf.{k}"], 1e-5, 1e-3, f"G buffer {k}")
+    G.eval()
+    with torch.no_grad():
+        ye = G(x)
+    assert_close(ye.cpu().numpy(), z[f"{name}.g.y_eval"], ABS, REL, "G eval forward")
+
+
+@pytest.mark.parametrize("case", NET_CASES, ids=[c[0] for c in NET_CASES])
+def test_discriminator_fp32_vs_reference(golden, case):
+    name, nd, ngf, ndf, n, h = case
+    z = golden("nets")
+    dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=2)
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(D, dst)
+    seed = int(z[f"{name}.d.seed"])
+    x = torch.from_numpy(fill.uniform(f"{name}.xd", (n, 6, h, h), seed=seed)).cuda().requires_grad_(True)
+    D.train()
+    y = D(x)
+    assert_close(y.detach().cpu().numpy(), z[f"{name}.d.y"], ABS, REL, "D train forward")
+    dy = torch.from_numpy(fill.uniform(f"{name}.d.dy", tuple(y.shape), seed=seed)).cuda()
+    for p in D.parameters():
+        p.grad = None
+    y.backward(dy)
+    grad_close(x.grad.cpu().numpy(), z[f"{name}.d.dx"], "D dx")
+    for k, p in D.named_parameters():
+        grad_close(fill.compact(p.grad.cpu().numpy()), z[f"{name}.d.grad.{k}"], f"D grad {k}")
+    for k, b in D.named_buffers():
+        assert_close(b.cpu().numpy(), z[f"{name}.d.buf.{k}"], 1e-5, 1e-3, f"D buffer {k}")
+    D.eval()
+    with torch.no_grad():
+        ye = D(x.detach())
+    assert_close(ye.cpu().numpy(), z[f"{name}.d.y_eval"], ABS, REL, "D eval forward")
+
+
+def _digest_ok(z, name, a, atol, rtol):
+    flat = np.asarray(a).reshape(-1)
+    stride = int(z[name + ".stride"])
+    assert flat.size == int(z[name + ".size"])
+    assert_close(flat[::stride][: z[name + ".sample"].size], z[name + ".sample"], atol, rtol, name + ".sample")
+    a64 = flat.astype(np.float64)
+    assert_close(np.abs(a64).sum(), z[name + ".abs_sum"], 0, 1e-3, name + ".abs_sum")
+    assert_close((a64 * a64).sum(), z[name + ".sq_sum"], 0, 1e-3, name + ".sq_sum")
+
+
+@pytest.mark.parametrize("tag,n,h", [("b2_128", 2, 128), ("b1_256", 1, 256)])
+def test_full_size_fp32_vs_reference(golden, tag, n, h):
+    """Default networks (num_downs=7, ngf=64; 41.8 M + 2.77 M parameters) at the reference's 256x256."""
+    z = golden("full")
+    G = pfa_gan.UNetGenerator(3, 3).cuda()
+    gst = fill.fill_state(nets.g_state_shapes(), seed=3)
+    load(G, gst)
+    x = torch.from_numpy(fill.uniform(f"full.{tag}.x", (n, 3, h, h))).cuda()
+    G.train()
+    with torch.no_grad():
+        y = G(x).cpu().numpy()
+    _digest_ok(z, f"full.{tag}.g.y", y, ABS, REL)
+    assert_close(y.astype(np.float64).mean(axis=(0, 2, 3)), z[f"full.{tag}.g.y_chan_mean"], 1e-4, 1e-3)
+    run = np.concatenate([b.cpu().numpy().reshape(-1) for k, b in G.named_buffers() if "running" in k])
+    _digest_ok(z, f"full.{tag}.g.running_cat", run, 1e-5, 1e-3)
+    load(G, gst)
+    G.eval()
+    with torch.no_grad():
+        ye = G(x).cpu().numpy()
+    _digest_ok(z, f"full.{tag}.g.y_eval", ye, ABS, REL)
+    D = pfa_gan.NLayerDiscriminator(6).cuda()
+    load(D, fill.fill_state(nets.d_state_shapes(), seed=4))
+    xd = torch.from_numpy(fill.uniform(f"full.{tag}.xd", (n, 6, h, h))).cuda()
+    D.train()
+    with torch.no_grad():
+        yd = D(xd).cpu().numpy()
+    assert_close(yd, z[f"full.{tag}.d.y"], ABS, REL, "D logits")
+
+
+def _check_step_state(z, name, G, D, tol_param=2e-5):
+    for prefix, m in (("g", G), ("d", D)):
+        for k, v in m.state_dict().items():
+            want = z[f"step.{name}.{prefix}.{k}"]
+            v = v.cpu().numpy()
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(want), k
+            elif ostep.is_param(k):
+                got = fill.compact(v)
+                frac_bad = np.mean(np.abs(got - want) > tol_param)
+                assert frac_bad < 0.02, f"{prefix}.{k}: {frac_bad:.2%} of parameters off by > {tol_param}"
+                assert np.abs(got - want).max() < 5e-4, f"{prefix}.{k}"
+            else:
+                assert_close(v, want, 1e-5, 2e-3, f"{prefix} buffer {k}")
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_fused_step_fp32_vs_reference(golden, case, use_graph):
+    """Two consecutive train_gan_one_epoch iterations of the reference vs GanTrainer (fused schedule)."""
+    name, nd, ngf, ndf, n, h, steps = case
+    z = golden("step")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+    load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+    tr = pfa_gan.GanTrainer(G, D, precision="fp32", use_graph=use_graph)
+    seed = int(z[f"step.{name}.seed"])
+    for i in range(steps):
+        a = torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).cuda()
+        b = torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).cuda()
+        losses = tr.step(a, b).cpu().numpy()
+        assert_close(losses[0], z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
+        assert_close(losses[1], z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
+        if not use_graph:
+            for k, p in G.named_parameters():
+                grad_close(fill.compact(p.grad.cpu().numpy()), z[f"step.{name}.ggrad{i}.{k}"], f"G grad {k} step {i}", 5e-3)
+    _check_step_state(z, name, G, D)
+    ld, lg = tr.epoch_losses()
+    assert_close(ld, np.mean([z[f"step.{name}.loss_d{i}"] for i in range(steps)]), 1e-4, 1e-4)
+
+
+def test_reference_style_loop_on_gpu_modules(golden):
+    """The reference's own call sequence (G(x).detach(), D(cat), loss.backward(), optim.Adam.step) on the
+    drop-in modules: every forward/backward is the HIP engine behind one autograd node per network."""
+    name, nd, ngf, ndf, n, h, steps = STEP_CASES[0]
+    z = golden("step")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+    load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+    og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    seed = int(z[f"step.{name}.seed"])
+    for i in range(steps):
+        batch = dict(image1=torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)),
+                     image2=torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)))
+        ld, lg = pfa_gan.train_gan_one_epoch(G, D, [batch], og, od)
+        assert_close(ld, z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
+        assert_close(lg, z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
+    _check_step_state(z, name, G, D)
+
+
+def test_checkpoint_layout_roundtrip():
+    """generator_epoch_*.pth contract (train_gan.py:149-153, generate_synthetic_data.py:46-48): plain
+    state_dict, reference key order, float32 NCHW-contiguous tensors; strict reload both ways."""
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+    x = torch.rand(2, 3, 32, 32, device="cuda") * 2 - 1
+    G(x)                                            # binds the flat arena, updates BN buffers
+    buf = io.BytesIO()
+    torch.save(G.state_dict(), buf)
+    buf.seek(0)
+    sd = torch.load(buf, map_location="cpu")
+    assert list(sd.keys()) == list(nets.g_state_shapes(3, 3, 5, 8).keys())
+    for k, v in sd.items():
+        assert v.is_contiguous(), k
+        assert v.dtype == (torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
+    G2 = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8)
+    G2.load_state_dict(sd, strict=True)             # CPU consumer (plain torch modules)
+    G.eval(), G2.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(G(x).cpu().numpy(), G2(x.cpu()).numpy(), atol=ABS, rtol=REL)
+    G3 = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+    G3(x)
+    G3.load_state_dict(sd, strict=True)             # into an already-bound GPU model
+    G3.eval()
+    with torch.no_grad():
+        np.testing.assert_array_equal(G(x).cpu().numpy(), G3(x).cpu().numpy())
+
+
+def test_bf16_mode_tracks_fp32(golden):
+    """Throughput mode: bf16 storage/operands, f32 accumulation.  The whole network cannot meet the fp32
+    gate (4.7e-2 max-abs for bf16 autocast on the reference itself); stated tolerance here:
+    max-abs 8e-2, mean-abs 1e-2 on the tanh output, losses within 2 %."""
+    name, nd, ngf, ndf, n, h = NET_CASES[1]
+    z = golden("nets")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda().set_precision("bf16")
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=1))
+    seed = int(z[f"{name}.g.seed"])
+    x = torch.from_numpy(fill.uniform(f"{name}.x", (n, 3, h, h), seed=seed)).cuda()
+    G.train()
+    with torch.no_grad():
+        y = G(x).cpu().numpy()
+    err = np.abs(y - z[f"{name}.g.y"])
+    assert err.max() < 8e-2 and err.mean() < 1e-2, (err.max(), err.mean())
+    sname, nd, ngf, ndf, n, h, steps = STEP_CASES[1]
+    zs = golden("step")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+    load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+    tr = pfa_gan.GanTrainer(G, D, precision="bf16")
+    seed = int(zs[f"step.{sname}.seed"])
+    for i in range(steps):
+        a = torch.from_numpy(fill.uniform(f"step.{sname}.a{i}", (n, 3, h, h), seed=seed)).cuda()
+        b = torch.from_numpy(fill.uniform(f"step.{sname}.b{i}", (n, 3, h, h), seed=seed)).cuda()
+        losses = tr.step(a, b).cpu().numpy()
+        assert_close(losses[0], zs[f"step.{sname}.loss_d{i}"], 0, 2e-2, f"bf16 loss_d step {i}")
+        assert_close(losses[1], zs[f"step.{sname}.loss_g{i}"], 0, 2e-2, f"bf16 loss_g step {i}")
+    for k, v in G.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(zs[f"step.{sname}.g.{k}"])
+
+
+def test_gpu_input_without_library_path_is_an_error(monkeypatch):
+    """No silent fallback: if the .so cannot be found the GPU path raises."""
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpfa_hip.so")
+    with pytest.raises(_lib.PfaError, match="mandatory"):
+        pfa_gan.kernels.pack_nhwc(torch.zeros(1, 3, 4, 4, device="cuda"), torch.float32)
