@@ -26,18 +26,43 @@ inline int grid_for(int64_t work, int block = 256, int cap = 256 * 16) {
 }
 
 // ------------------------------------------------------------------ BatchNorm statistics
-__global__ void k_bn_finalize(const float* __restrict__ psum, const float* __restrict__ psq, int ntiles, int c,
-                              double count, const float* gamma, const float* beta, float eps, float momentum,
-                              int repeats, float* running_mean, float* running_var, int64_t* nbt, float* scale,
-                              float* shift, float* mean_out, float* invstd_out) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch == 0 && nbt) *nbt += repeats;
-    if (ch >= c) return;
+// Block = 8 channels x 32 tile-lanes: the per-tile partials are summed in parallel (double), then one lane
+// per channel finishes.  Deterministic: fixed tile -> lane assignment and a fixed-order LDS tree.
+constexpr int FIN_CH = 8, FIN_LANES = 32;
+__device__ __forceinline__ void tile_sum2(const float* __restrict__ a, const float* __restrict__ b, int ntiles, int c,
+                                          int ch, bool valid, double (*sh)[FIN_LANES][FIN_CH], double& ra, double& rb) {
+    const int cl = threadIdx.x % FIN_CH, tl = threadIdx.x / FIN_CH;
     double s = 0.0, q = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
-        s += (double)psum[(size_t)t * c + ch];
-        q += (double)psq[(size_t)t * c + ch];
+    if (valid)
+        for (int t = tl; t < ntiles; t += FIN_LANES) {
+            s += (double)a[(size_t)t * c + ch];
+            q += (double)b[(size_t)t * c + ch];
+        }
+    sh[0][tl][cl] = s;
+    sh[1][tl][cl] = q;
+    __syncthreads();
+    for (int off = FIN_LANES / 2; off > 0; off >>= 1) {
+        if (tl < off) {
+            sh[0][tl][cl] += sh[0][tl + off][cl];
+            sh[1][tl][cl] += sh[1][tl + off][cl];
+        }
+        __syncthreads();
     }
+    ra = sh[0][0][cl];
+    rb = sh[1][0][cl];
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                     int ntiles, int c, double count, const float* gamma,
+                                                     const float* beta, float eps, float momentum, int repeats,
+                                                     float* running_mean, float* running_var, int64_t* nbt,
+                                                     float* scale, float* shift, float* mean_out, float* invstd_out) {
+    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    const int ch = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += repeats;
+    double s, q;
+    tile_sum2(psum, psq, ntiles, c, ch, ch < c, sh, s, q);
+    if (threadIdx.x >= FIN_CH || ch >= c) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -151,16 +176,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw
     }
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ part, int ntiles, int c, double count,
-                                  const float* gamma, const float* mean, const float* invstd, float* dgamma,
-                                  float* dbeta, float* coef) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double sdy = 0.0, sdyx = 0.0;
-    for (int t = 0; t < ntiles; ++t) {
-        sdy += (double)part[(size_t)t * c + ch];
-        sdyx += (double)part[((size_t)ntiles + t) * c + ch];
-    }
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ part, int ntiles, int c,
+                                                         double count, const float* gamma, const float* mean,
+                                                         const float* invstd, float* dgamma, float* dbeta,
+                                                         float* coef) {
+    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    const int ch = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double sdy, sdyx;
+    tile_sum2(part, part + (size_t)ntiles * c, ntiles, c, ch, ch < c, sh, sdy, sdyx);
+    if (threadIdx.x >= FIN_CH || ch >= c) return;
     if (dgamma) dgamma[ch] += (float)sdyx;       // gradients accumulate into a zeroed arena (zero_grad semantics)
     if (dbeta) dbeta[ch] += (float)sdy;
     const double g = gamma ? (double)gamma[ch] : 1.0;
@@ -260,24 +284,44 @@ __global__ __launch_bounds__(256) void k_l1_tanh_bwd(const T* __restrict__ fake,
 }
 
 // ------------------------------------------------------------------ column sums
-constexpr int COLSUM_ROWS = 256;
+// Pass 1: at most COLSUM_BLOCKS blocks; a lane owns one 16-byte column chunk and strides over rows, the
+// per-column partials of a block are combined through LDS.  Pass 2: tile_sum over the block partials.
+constexpr int COLSUM_BLOCKS = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, int64_t rows, int c, float* ws) {
-    // block = COLSUM_ROWS rows; thread t owns columns t, t+256, ...
-    const int64_t r0 = (int64_t)blockIdx.x * COLSUM_ROWS;
-    const int64_t r1 = r0 + COLSUM_ROWS < rows ? r0 + COLSUM_ROWS : rows;
-    for (int col = threadIdx.x; col < c; col += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * c + col]);
-        ws[(size_t)blockIdx.x * c + col] = s;
+__global__ __launch_bounds__(256) void k_colsum_partial(const T* __restrict__ x, int64_t rows, int c, int cpr,
+                                                        float* ws) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ float red[256][CH];
+    const int tid = threadIdx.x;
+    const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
+    float s[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) s[e] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * rpp + rsub; row < rows; row += (int64_t)gridDim.x * rpp) {
+        Chunk<T> v;
+        v.load(x + (row * cpr + col) * CH);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) s[e] += v.v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < CH; ++e) red[tid][e] = s[e];
+    __syncthreads();
+    if (tid < cpr) {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            float a = 0.f;
+            for (int r = 0; r < rpp; ++r) a += red[r * cpr + tid][e];
+            ws[(size_t)blockIdx.x * c + tid * CH + e] = a;
+        }
     }
 }
-__global__ void k_colsum_final(const float* __restrict__ ws, int nblk, int c, int c_out, float* out) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c_out) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * c + col];
-    out[col] += (float)s;
+__global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ ws, int nblk, int c, int c_out,
+                                                      float* out) {
+    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    const int ch = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    double s, unused;
+    tile_sum2(ws, ws, nblk, c, ch, ch < c_out, sh, s, unused);
+    if (threadIdx.x < FIN_CH && ch < c_out) out[ch] += (float)s;
 }
 
 // ------------------------------------------------------------------ Adam
@@ -394,7 +438,7 @@ extern "C" int pfa_bn_finalize(const float* psum, const float* psq, int ntiles, 
                                float* running_mean, float* running_var, int64_t* nbt, float* scale, float* shift,
                                float* mean, float* invstd, pfa_stream s) {
     PFA_REQUIRE(psum && psq && scale && shift && ntiles > 0 && c > 0 && count > 0, "pfa_bn_finalize: bad arguments");
-    hipLaunchKernelGGL(k_bn_finalize, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)s, psum, psq, ntiles, c, count,
+    hipLaunchKernelGGL(k_bn_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)s, psum, psq, ntiles, c, count,
                        gamma, beta, eps, momentum, repeats, running_mean, running_var, nbt, scale, shift, mean, invstd);
     PFA_LAUNCHED("k_bn_finalize");
     return 0;
@@ -459,7 +503,7 @@ extern "C" int pfa_bn_bwd_finalize(const float* part, int ntiles, int c, double 
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef,
                                    pfa_stream s) {
     PFA_REQUIRE(part && mean && invstd && coef && ntiles > 0 && c > 0, "pfa_bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((c + 63) / 64), dim3(64), 0, (hipStream_t)s, part, ntiles, c, count,
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)s, part, ntiles, c, count,
                        gamma, mean, invstd, dgamma, dbeta, coef);
     PFA_LAUNCHED("k_bn_bwd_finalize");
     return 0;
@@ -509,21 +553,26 @@ extern "C" int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count
     return 0;
 }
 
-extern "C" size_t pfa_colsum_ws(int64_t rows, int c) {
-    return (size_t)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS) * (size_t)c;
-}
+extern "C" size_t pfa_colsum_ws(int64_t rows, int c) { return (size_t)COLSUM_BLOCKS * (size_t)c; }
 
 extern "C" int pfa_colsum(const void* x, int64_t rows, int c, int c_out, int dtype, float* out, float* ws,
                           pfa_stream s) {
     PFA_REQUIRE(x && out && ws && rows > 0 && c > 0 && c_out > 0 && c_out <= c, "pfa_colsum: bad arguments");
-    const int nblk = (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS);
+    const int ch = pfa_ch(dtype);
+    PFA_REQUIRE(c % ch == 0, "pfa_colsum: c=%d not a multiple of %d", c, ch);
+    const int cpr = c / ch;
+    PFA_REQUIRE(cpr <= 256 && 256 % cpr == 0, "pfa_colsum: c/%d = %d must divide 256", ch, cpr);
+    const int rpp = 256 / cpr;
+    int nblk = (int)((rows + rpp - 1) / rpp);
+    if (nblk > COLSUM_BLOCKS) nblk = COLSUM_BLOCKS;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(k_colsum_partial<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x,
-                                  rows, c, ws),
+                                  rows, c, cpr, ws),
                hipLaunchKernelGGL(k_colsum_partial<float>, dim3(nblk), dim3(256), 0, (hipStream_t)s, (const float*)x,
-                                  rows, c, ws));
+                                  rows, c, cpr, ws));
     PFA_LAUNCHED("k_colsum_partial");
-    hipLaunchKernelGGL(k_colsum_final, dim3((c_out + 63) / 64), dim3(64), 0, (hipStream_t)s, ws, nblk, c, c_out, out);
+    hipLaunchKernelGGL(k_colsum_final, dim3((c_out + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)s, ws, nblk, c,
+                       c_out, out);
     PFA_LAUNCHED("k_colsum_final");
     return 0;
 }

@@ -298,13 +298,60 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
 }
 
 // ---------------------------------------------------------------- split-K finish
-// out[pix][n] = act(bias + sum_s slab[s][pix][n]); optional BatchNorm partial statistics per 64-row tile.
+// out[pix][n] = act(bias + sum_s slab[s][pix][n]); optional BatchNorm partial statistics per row tile.
+// Fast path: one float4 column chunk per lane (consecutive lanes = consecutive chunks of a row, coalesced),
+// 256/cpr rows per pass, FIN_PASSES passes per block, per-column partial sums reduced through LDS.
+constexpr int FIN_PASSES = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restrict__ slab, int splitk, int pixels,
+                                                           int n, int n1, const float* __restrict__ bias, int act,
+                                                           float slope, char* out1, int ld1, char* out2, int ld2,
+                                                           float* psum, float* psq, int cpr) {
+    __shared__ float red[2][256][4];
+    const int tid = threadIdx.x;
+    const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
+    const int c0 = col * 4;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *(const f32x4*)(bias + c0);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
+    const size_t row0 = (size_t)blockIdx.x * rpp * FIN_PASSES;
+    const size_t plane = (size_t)pixels * n;
+#pragma unroll 2
+    for (int ps = 0; ps < FIN_PASSES; ++ps) {
+        const size_t row = row0 + (size_t)ps * rpp + rsub;
+        if (row >= (size_t)pixels) break;
+        const float* src = slab + row * n + c0;
+        f32x4 v = bv;
+        for (int k = 0; k < splitk; ++k) v += *(const f32x4*)(src + k * plane);
+        s += v;
+        q += v * v;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = apply_act(v[e], act == PFA_ACT_TANH ? PFA_ACT_NONE : act, slope);
+        if (c0 < n1) store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
+        else store4<T>(out2 + (row * ld2 + (c0 - n1)) * sizeof(T), o);
+    }
+    if (!psum) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; }
+    __syncthreads();
+    if (tid < cpr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f, b = 0.f;
+            for (int r = 0; r < rpp; ++r) { a += red[0][r * cpr + tid][e]; b += red[1][r * cpr + tid][e]; }
+            psum[(size_t)blockIdx.x * n + tid * 4 + e] = a;
+            psq[(size_t)blockIdx.x * n + tid * 4 + e] = b;
+        }
+    }
+}
+
+// Generic path (any n): block = 64 rows, thread t walks columns t, t+256, ...
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slab, int splitk, int pixels, int n,
                                                        int n1, const float* __restrict__ bias, int act, float slope,
                                                        char* out1, int ld1, char* out2, int ld2, float* psum,
                                                        float* psq) {
-    // block = 64 rows; thread t walks columns t, t+256, ... of each row (coalesced over n)
     const int row0 = blockIdx.x * 64;
     const int rows = min(64, pixels - row0);
     // a single output also gets its pad channels [n, ld1) written (zeros), like the direct epilogue does
@@ -329,6 +376,15 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
             psq[(size_t)blockIdx.x * n + col] = q;
         }
     }
+}
+
+// rows of a [pixels][n] slab one finish block covers, and whether the vector path applies
+inline bool finish_vec_ok(int n, int n1, int ld1, int act) {
+    const int cpr = n / 4;
+    return n % 4 == 0 && cpr >= 1 && cpr <= 256 && 256 % cpr == 0 && act != PFA_ACT_TANH && (n1 >= n ? ld1 == n : true);
+}
+inline int finish_rows_per_block(int n, int n1, int ld1, int act) {
+    return finish_vec_ok(n, n1, ld1, act) ? (256 / (n / 4)) * FIN_PASSES : 64;
 }
 
 int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
@@ -384,7 +440,10 @@ inline int bm_of(int bn) { return bn == 16 ? 256 : 128; }
 extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
-    if (k.splitk > 1) return (k.npix + 63) / 64;
+    if (k.splitk > 1) {
+        const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act);
+        return (k.npix + rpb - 1) / rpb;
+    }
     const int bm = bm_of(pick_bn(k.n));
     return classes * ((k.M + bm - 1) / bm);
 }
@@ -409,15 +468,26 @@ extern "C" int pfa_splitk_finish(const float* slab, int splitk, int pixels, int 
                                  float* psq, int* ntiles_stat, pfa_stream s) {
     PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0, "pfa_splitk_finish: bad arguments");
     PFA_REQUIRE(n1 >= n || out2, "pfa_splitk_finish: out2 missing");
-    const int tiles = (pixels + 63) / 64;
+    PFA_REQUIRE(dtype == PFA_F32 || dtype == PFA_BF16, "pfa_splitk_finish: bad dtype");
+    const bool vec = finish_vec_ok(n, n1, ld1, act) && n1 % 4 == 0;
+    const int rpb = vec ? (256 / (n / 4)) * FIN_PASSES : 64;
+    const int tiles = (pixels + rpb - 1) / rpb;
     if (ntiles_stat) *ntiles_stat = tiles;
     hipStream_t st = (hipStream_t)s;
-    if (dtype == PFA_BF16)
+    if (vec) {
+        if (dtype == PFA_BF16)
+            hipLaunchKernelGGL(k_splitk_finish_vec<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4);
+        else
+            hipLaunchKernelGGL(k_splitk_finish_vec<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4);
+    } else if (dtype == PFA_BF16) {
         hipLaunchKernelGGL(k_splitk_finish<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
                            act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
-    else
+    } else {
         hipLaunchKernelGGL(k_splitk_finish<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
                            act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
+    }
     PFA_LAUNCHED("k_splitk_finish");
     return 0;
 }

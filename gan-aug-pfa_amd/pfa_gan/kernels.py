@@ -107,7 +107,9 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
         a.slab = ptr(ws.get("slab", a.splitk * npix * n))
     psum = psq = None
     if stats:
-        tiles = max(math.ceil(npix / 64), 4 * math.ceil(M / 128)) + 4
+        tiles = lib().pfa_gather_stat_tiles(ctypes.byref(a))
+        if tiles < 0:
+            check(tiles, "pfa_gather_stat_tiles")
         psum = ws.get("psum", tiles * n)
         psq = ws.get("psq", tiles * n)
         a.psum, a.psq = ptr(psum), ptr(psq)
