@@ -30,6 +30,7 @@ struct GatherK {
     float* psum;
     float* psq;
     float* slab;
+    int slab_ld;
     int mode, nb, hq, wq, hs, ws;
     int c1, c2, ctot;
     int cpt, cpt_shift, ktot, ksteps;
@@ -38,6 +39,7 @@ struct GatherK {
     int splitk, kper;
     int act;
     float slope;
+    int mtiles, ntiles, nwg;
 };
 
 template <typename T> struct Mma;
@@ -81,9 +83,13 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    const int split = blockIdx.z % p.splitk, cls = blockIdx.z / p.splitk;
+    // work list order: n-tile fastest (blocks sharing an activation tile are neighbours), then m-tile, then class/slice
+    unsigned wid = xcd_remap(blockIdx.x, p.nwg);
+    const int nt = wid % p.ntiles; wid /= p.ntiles;
+    const int mt = wid % p.mtiles; wid /= p.mtiles;
+    const int split = wid % p.splitk, cls = wid / p.splitk;
     const int py = cls >> 1, px = cls & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = mt * BM, n0 = nt * BN;
     const char* zero = (const char*)g_pfa_zero_page;
 
     // ---- staging roles: this thread fills chunk slot `cs` of rows r0 + 32*i
@@ -218,10 +224,10 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
-            if (nbase < p.n) {
+            if (nbase < p.slab_ld) {
 #pragma unroll
                 for (int b = 0; b < FM; ++b)
-                    if (mval[b]) *(f32x4*)(p.slab + ((size_t)split * p.npix + opix[b]) * p.n + nbase) = acc[a][b];
+                    if (mval[b]) *(f32x4*)(p.slab + ((size_t)split * p.npix + opix[b]) * p.slab_ld + nbase) = acc[a][b];
             }
         }
         return;
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i) { s += red[i * BN + tid]; q += red[(WM + i) * BN + tid]; }
-            const size_t trow = (size_t)cls * gridDim.x + blockIdx.x;
+            const size_t trow = (size_t)cls * p.mtiles + mt;
             p.psum[trow * p.n + n0 + tid] = s;
             p.psq[trow * p.n + n0 + tid] = q;
         }
@@ -306,7 +312,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restrict__ slab, int splitk, int pixels,
                                                            int n, int n1, const float* __restrict__ bias, int act,
                                                            float slope, char* out1, int ld1, char* out2, int ld2,
-                                                           float* psum, float* psq, int cpr) {
+                                                           float* psum, float* psq, int cpr, int passes) {
     __shared__ float red[2][256][4];
     const int tid = threadIdx.x;
     const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
@@ -314,10 +320,9 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *(const f32x4*)(bias + c0);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-    const size_t row0 = (size_t)blockIdx.x * rpp * FIN_PASSES;
+    const size_t row0 = (size_t)blockIdx.x * rpp * passes;
     const size_t plane = (size_t)pixels * n;
-#pragma unroll 2
-    for (int ps = 0; ps < FIN_PASSES; ++ps) {
+    for (int ps = 0; ps < passes; ++ps) {
         const size_t row = row0 + (size_t)ps * rpp + rsub;
         if (row >= (size_t)pixels) break;
         const float* src = slab + row * n + c0;
@@ -351,7 +356,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__ slab, int splitk, int pixels, int n,
                                                        int n1, const float* __restrict__ bias, int act, float slope,
                                                        char* out1, int ld1, char* out2, int ld2, float* psum,
-                                                       float* psq) {
+                                                       float* psq, int slab_ld) {
     const int row0 = blockIdx.x * 64;
     const int rows = min(64, pixels - row0);
     // a single output also gets its pad channels [n, ld1) written (zeros), like the direct epilogue does
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
             const size_t pix = row0 + r;
             float v = bv;
             if (real)
-                for (int k = 0; k < splitk; ++k) v += slab[((size_t)k * pixels + pix) * n + col];
+                for (int k = 0; k < splitk; ++k) v += slab[((size_t)k * pixels + pix) * slab_ld + col];
             s += v;
             q += v * v;
             v = apply_act(v, act, slope);
@@ -378,13 +383,38 @@ __global__ __launch_bounds__(256) void k_splitk_finish(const float* __restrict__
     }
 }
 
+// Few output channels (the 1-channel logit conv, the 3-channel image conv): one lane per (pixel, channel).
+template <typename T>
+__global__ __launch_bounds__(256) void k_splitk_finish_small(const float* __restrict__ slab, int splitk, int pixels,
+                                                             int n, const float* __restrict__ bias, int act,
+                                                             float slope, T* out, int ld, int slab_ld) {
+    const size_t total = (size_t)pixels * ld;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t pix = idx / ld;
+        const int col = (int)(idx - pix * ld);
+        float v = 0.f;
+        if (col < n) {
+            v = bias ? bias[col] : 0.f;
+            for (int k = 0; k < splitk; ++k) v += slab[((size_t)k * pixels + pix) * slab_ld + col];
+            v = apply_act(v, act, slope);
+        }
+        out[idx] = from_f32<T>(v);
+    }
+}
+
 // rows of a [pixels][n] slab one finish block covers, and whether the vector path applies
 inline bool finish_vec_ok(int n, int n1, int ld1, int act) {
     const int cpr = n / 4;
     return n % 4 == 0 && cpr >= 1 && cpr <= 256 && 256 % cpr == 0 && act != PFA_ACT_TANH && (n1 >= n ? ld1 == n : true);
 }
-inline int finish_rows_per_block(int n, int n1, int ld1, int act) {
-    return finish_vec_ok(n, n1, ld1, act) ? (256 / (n / 4)) * FIN_PASSES : 64;
+// passes per block: fewer when there are few pixels, so that the grid still covers the chip
+inline int finish_passes(int n, int pixels) {
+    const int rpp = 256 / (n / 4);
+    int passes = pixels / (rpp * 512);
+    return passes < 1 ? 1 : (passes > FIN_PASSES ? FIN_PASSES : passes);
+}
+inline int finish_rows_per_block(int n, int n1, int ld1, int act, int pixels) {
+    return finish_vec_ok(n, n1, ld1, act) ? (256 / (n / 4)) * finish_passes(n, pixels) : 64;
 }
 
 int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
@@ -420,9 +450,8 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.kper = (k.ksteps + k.splitk - 1) / k.splitk;
     k.splitk = (k.ksteps + k.kper - 1) / k.kper;     // no empty slices
     k.act = a->act; k.slope = a->slope;
-    if (k.splitk > 1) {
-        PFA_REQUIRE(a->slab && a->n % 4 == 0, "pfa_gather_gemm: split-K needs a slab and n %% 4 == 0");
-    }
+    k.slab_ld = (a->n + 3) & ~3;
+    if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of splitk*pixels*round4(n) floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
@@ -441,7 +470,7 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
     if (k.splitk > 1) {
-        const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act);
+        const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act, k.npix);
         return (k.npix + rpb - 1) / rpb;
     }
     const int bm = bm_of(pick_bn(k.n));
@@ -449,8 +478,11 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-static int launch_gather(const GatherK& k, int classes, hipStream_t st) {
-    dim3 grid((k.M + BM - 1) / BM, (k.n + BN - 1) / BN, classes * k.splitk);
+static int launch_gather(GatherK k, int classes, hipStream_t st) {
+    k.mtiles = (k.M + BM - 1) / BM;
+    k.ntiles = (k.n + BN - 1) / BN;
+    k.nwg = k.mtiles * k.ntiles * classes * k.splitk;
+    dim3 grid(k.nwg);
     const size_t lds = 2 * (BM * 128 + BN * 128);
     static bool attr_done = false;
     if (!attr_done) {
@@ -463,30 +495,40 @@ static int launch_gather(const GatherK& k, int classes, hipStream_t st) {
     return 0;
 }
 
-extern "C" int pfa_splitk_finish(const float* slab, int splitk, int pixels, int n, int n1, const float* bias, int act,
-                                 float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum,
-                                 float* psq, int* ntiles_stat, pfa_stream s) {
-    PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0, "pfa_splitk_finish: bad arguments");
+extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1,
+                                 const float* bias, int act, float slope, int dtype, void* out1, int ld1, void* out2,
+                                 int ld2, float* psum, float* psq, int* ntiles_stat, pfa_stream s) {
+    PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0 && slab_ld >= n, "pfa_splitk_finish: bad arguments");
     PFA_REQUIRE(n1 >= n || out2, "pfa_splitk_finish: out2 missing");
     PFA_REQUIRE(dtype == PFA_F32 || dtype == PFA_BF16, "pfa_splitk_finish: bad dtype");
-    const bool vec = finish_vec_ok(n, n1, ld1, act) && n1 % 4 == 0;
-    const int rpb = vec ? (256 / (n / 4)) * FIN_PASSES : 64;
+    const bool vec = finish_vec_ok(n, n1, ld1, act) && n1 % 4 == 0 && slab_ld == n;
+    const bool small = !vec && n1 >= n && ld1 <= 16 && !psum;
+    const int passes = vec ? finish_passes(n, pixels) : 1;
+    const int rpb = vec ? (256 / (n / 4)) * passes : 64;
     const int tiles = (pixels + rpb - 1) / rpb;
     if (ntiles_stat) *ntiles_stat = tiles;
     hipStream_t st = (hipStream_t)s;
     if (vec) {
         if (dtype == PFA_BF16)
             hipLaunchKernelGGL(k_splitk_finish_vec<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes);
         else
             hipLaunchKernelGGL(k_splitk_finish_vec<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes);
+    } else if (small) {
+        const int grid = (int)(((size_t)pixels * ld1 + 255) / 256);
+        if (dtype == PFA_BF16)
+            hipLaunchKernelGGL(k_splitk_finish_small<bf16_t>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, slab,
+                               splitk, pixels, n, bias, act, slope, (bf16_t*)out1, ld1, slab_ld);
+        else
+            hipLaunchKernelGGL(k_splitk_finish_small<float>, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, st, slab,
+                               splitk, pixels, n, bias, act, slope, (float*)out1, ld1, slab_ld);
     } else if (dtype == PFA_BF16) {
         hipLaunchKernelGGL(k_splitk_finish<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
-                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
+                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, slab_ld);
     } else {
         hipLaunchKernelGGL(k_splitk_finish<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1, bias,
-                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq);
+                           act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, slab_ld);
     }
     PFA_LAUNCHED("k_splitk_finish");
     return 0;
@@ -513,7 +555,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     if (k.splitk > 1) {
         int tiles = 0;
         // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n
-        rc = pfa_splitk_finish(k.slab, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
+        rc = pfa_splitk_finish(k.slab, k.slab_ld, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
                                k.out2, k.ld2, k.psum, k.psq, &tiles, s);
         if (rc) return rc;
         a->ntiles_stat = tiles;

@@ -112,6 +112,14 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) {
     }
 }
 
+// XCD-aware work-item id (cdna guide T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs,
+// each with a private L2: give every XCD one CONTIGUOUS chunk of the work list so that workgroups which share an
+// operand tile hit the same L2.  Placement only changes speed, never results.
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // 256 bytes of zeros in the code object: out-of-image taps, K tails and missing weight rows
 // point their LDS-DMA source here instead of branching.
 // (static: each translation unit carries its own copy, so no relocatable device code is needed.)

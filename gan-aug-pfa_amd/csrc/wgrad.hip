@@ -31,6 +31,7 @@ struct WgradK {
     int M, mper;
     unsigned magic_hw, magic_wq;
     int jtot;        // 16 * gp
+    int jtiles, itiles, nwg;
 };
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
@@ -58,8 +59,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave % WI, wj = wave / WI;
-    const int j0 = blockIdx.x * BJ, i0 = blockIdx.y * BI;
-    const int mbeg = blockIdx.z * p.mper;
+    // work list: j-tile fastest (neighbours share the direct tile and overlapping gathered pixels), then i-tile,
+    // then reduction slice; each XCD takes one contiguous chunk of it
+    unsigned wid = xcd_remap(blockIdx.x, p.nwg);
+    const int jt = wid % p.jtiles; wid /= p.jtiles;
+    const int it = wid % p.itiles; wid /= p.itiles;
+    const int j0 = jt * BJ, i0 = it * BI;
+    const int mbeg = (int)wid * p.mper;
     const int mend = min(p.M, mbeg + p.mper);
     const char* zero = (const char*)g_pfa_zero_page;
 
@@ -225,10 +231,13 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 }
 
 template <typename T, int BI, int WI, int WJ>
-int launch_wgrad(const WgradK& k, int msplit, hipStream_t st) {
+int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
     constexpr int KM = sizeof(T) == 2 ? 64 : 32;
     constexpr size_t lds = 2 * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
-    dim3 grid((k.jtot + 127) / 128, (k.dp + BI - 1) / BI, msplit);
+    k.jtiles = (k.jtot + 127) / 128;
+    k.itiles = (k.dp + BI - 1) / BI;
+    k.nwg = k.jtiles * k.itiles * msplit;
+    dim3 grid(k.nwg);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -44,7 +44,7 @@ PROTOTYPES = {
     "pfa_launch_count": (c_uint64, []),
     "pfa_gather_stat_tiles": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_gemm": (c_int, [POINTER(GatherArgs), c_void_p]),
-    "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
+    "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pfa_wgrad": (c_int, [POINTER(WgradArgs), c_void_p]),
     "pfa_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,

@@ -73,7 +73,7 @@ def choose_splitk(mode, M, n, ctot, dtype):
     classes = 4 if mode == TCONV_S2 else 1
     blocks = math.ceil(M / bm) * math.ceil(n / bn) * classes
     ksteps = math.ceil((4 if mode == TCONV_S2 else 16) * (ctot // ch_of(dtype)) / 8)
-    if blocks >= 192 or ksteps < 8 or n % 4:
+    if blocks >= 192 or ksteps < 8:
         return 1
     return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
 
@@ -104,7 +104,7 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     a.out1, a.out2 = ptr(outs[0]), ptr(outs[1]) if len(outs) > 1 else None
     npix = outs[0].shape[0] * outs[0].shape[1] * outs[0].shape[2]
     if a.splitk > 1:
-        a.slab = ptr(ws.get("slab", a.splitk * npix * n))
+        a.slab = ptr(ws.get("slab", a.splitk * npix * ((n + 3) // 4 * 4)))
     psum = psq = None
     if stats:
         tiles = lib().pfa_gather_stat_tiles(ctypes.byref(a))
@@ -136,7 +136,8 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None):
         km = 64 if direct[0].dtype == torch.bfloat16 else 32
         M = a.nb * a.hq * a.wq
         tiles = math.ceil(16 * (a.g1p + a.g2p) / 128) * math.ceil((a.d1p + a.d2p) / 128)
-        msplit = max(1, min(math.ceil(M / km / 4), math.ceil(768 / tiles)))
+        # ~2 workgroups per CU; every extra slice costs one more float32-atomic pass over dw (chip-wide ~1.3 TB/s)
+        msplit = max(1, min(math.ceil(M / km / 8), math.ceil(512 / tiles)))
     a.msplit = msplit
     a.dir1, a.dir2 = ptr(direct[0]), ptr(direct[1]) if len(direct) > 1 else None
     a.gat1, a.gat2 = ptr(gathered[0]), ptr(gathered[1]) if len(gathered) > 1 else None

@@ -80,17 +80,17 @@ typedef struct pfa_gather_args {
     void* out2;
     float* psum;                 /* optional BatchNorm partial sums   [tiles][n]    */
     float* psq;                  /* optional partial sums of squares  [tiles][n]    */
-    float* slab;                 /* splitk>1: float32 [splitk][pixels][n] workspace */
+    float* slab;                 /* splitk>1: float32 [splitk][pixels][round4(n)] workspace */
 } pfa_gather_args;
 
 /* Tiles of partial statistics a call will write (rows of psum/psq) for this geometry. */
 int pfa_gather_stat_tiles(const pfa_gather_args* a);
 int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s);
 
-/* Sum split-K slabs, add bias, emit statistics partials, activate, store.  `pixels` rows. */
-int pfa_splitk_finish(const float* slab, int splitk, int pixels, int n, int n1, const float* bias, int act,
-                      float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
-                      int* ntiles_stat, pfa_stream s);
+/* Sum split-K slabs [splitk][pixels][slab_ld], add bias, emit statistics partials, activate, store. */
+int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1, const float* bias,
+                      int act, float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum,
+                      float* psq, int* ntiles_stat, pfa_stream s);
 
 /* ------------------------------------------------------------------ weight gradient, MFMA
  * dw[i][tap][c] (+)= sum_m direct[m][i] * gathered[pix(m)+tap][c]     (float32 accumulate)
