@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const T* __restrict__ g1,
                                                        int act1, const T* __restrict__ g2, int act2, float slope,
-                                                       T* dy, float* part, int ntiles) {
+                                                       T* dy, float* part, int ntiles, int passes) {
     constexpr int CH = ElemTraits<T>::CH;
     __shared__ float red[2][256][CH];
     const int tid = threadIdx.x;
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw
         s_dy[e] = 0.f;
         s_dyx[e] = 0.f;
     }
-    const int64_t row0 = (int64_t)blockIdx.x * rpp * BWD_PASSES;
-    for (int ps = 0; ps < BWD_PASSES; ++ps) {
+    const int64_t row0 = (int64_t)blockIdx.x * rpp * passes;
+    for (int ps = 0; ps < passes; ++ps) {
         const int64_t row = row0 + (int64_t)ps * rpp + rsub;
         if (row >= rows) break;
         const int64_t off = (row * cpr + col) * CH;
@@ -468,6 +468,13 @@ extern "C" int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const
     return 0;
 }
 
+// rows per block: fewer passes for small tensors so that even a 4x4 map spreads over the chip
+static int bwd_passes(int64_t rows, int cpr) {
+    const int rpp = 256 / cpr;
+    int64_t p = rows / ((int64_t)rpp * 1024);
+    return p < 1 ? 1 : (p > BWD_PASSES ? BWD_PASSES : (int)p);
+}
+
 extern "C" int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype, const float* scale,
                                  const float* shift, const float* mean, const float* invstd, const void* g1, int act1,
                                  const void* g2, int act2, float slope, void* dy, float* part, int* ntiles,
@@ -478,16 +485,17 @@ extern "C" int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype
     const int cpr = c / ch;
     PFA_REQUIRE(cpr <= 256 && 256 % cpr == 0, "pfa_bn_bwd_reduce: c/%d = %d must divide 256", ch, cpr);
     PFA_REQUIRE((mean == nullptr) == (part == nullptr), "pfa_bn_bwd_reduce: mean and part come together");
-    const int rows_per_block = (256 / cpr) * BWD_PASSES;
+    const int passes = bwd_passes(rows, cpr);
+    const int rows_per_block = (256 / cpr) * passes;
     const int tiles = (int)((rows + rows_per_block - 1) / rows_per_block);
     if (ntiles) *ntiles = tiles;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(tiles), dim3(256), 0, (hipStream_t)s,
                                   (const bf16_t*)raw, rows, c, cpr, scale, shift, mean, invstd, (const bf16_t*)g1, act1,
-                                  (const bf16_t*)g2, act2, slope, (bf16_t*)dy, part, tiles),
+                                  (const bf16_t*)g2, act2, slope, (bf16_t*)dy, part, tiles, passes),
                hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(tiles), dim3(256), 0, (hipStream_t)s, (const float*)raw,
                                   rows, c, cpr, scale, shift, mean, invstd, (const float*)g1, act1, (const float*)g2,
-                                  act2, slope, (float*)dy, part, tiles));
+                                  act2, slope, (float*)dy, part, tiles, passes));
     PFA_LAUNCHED("k_bn_bwd_reduce");
     return 0;
 }
@@ -495,7 +503,7 @@ extern "C" int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype
 extern "C" int pfa_bn_bwd_tiles(int64_t rows, int c, int dtype) {
     const int cpr = c / pfa_ch(dtype);
     if (cpr < 1 || cpr > 256 || 256 % cpr) return -1;
-    const int rows_per_block = (256 / cpr) * BWD_PASSES;
+    const int rows_per_block = (256 / cpr) * bwd_passes(rows, cpr);
     return (int)((rows + rows_per_block - 1) / rows_per_block);
 }
 

@@ -20,6 +20,8 @@
 
 namespace {
 
+int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits
+
 struct GatherK {
     const char* src1;
     const char* src2;
@@ -40,6 +42,8 @@ struct GatherK {
     int act;
     float slope;
     int mtiles, ntiles, nwg;
+    int wide, spt, sp1;      // wide path: K-steps per tap, K-steps of a tap that come from src1
+    int dbg;                 // ablation bits (pfa_set_knob 1): 1 no output stores, 2 no stats, 4 no MFMA, 8 no DMA
 };
 
 template <typename T> struct Mma;
@@ -70,14 +74,23 @@ template <> __device__ __forceinline__ void store4<bf16_t>(char* p, const float*
     *(bf16x4*)p = t;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
+#define PFA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// STAGES == 2: two LDS buffers, __syncthreads() per K-step (drains the DMA queue at every barrier).
+// STAGES == 3: ring of three buffers; the loads of K-step i+2 are issued while step i computes and are
+//              retired by a COUNTED s_waitcnt vmcnt + raw s_barrier, so a full K-step of DMA stays in
+//              flight across each barrier (cdna guide 5, "Pipelining across barriers").
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
     constexpr int CH = ElemTraits<T>::CH;
+    constexpr int NT = 64 * WM * WN;                       // threads
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int AROWS = BM / 32;
-    constexpr int WROWS = BN >= 32 ? BN / 32 : 1;
-    static_assert(WM * WN == 4 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
+    constexpr int RSTEP = NT / 8;                          // tile rows covered by one staging pass
+    constexpr int AROWS = BM / RSTEP;
+    constexpr int WROWS = BN >= RSTEP ? BN / RSTEP : 1;
+    constexpr int WWAVES = BN >= RSTEP ? NT / 64 : BN / 8; // waves that take part in staging the weight tile
+    static_assert(TM % 16 == 0 && TN % 16 == 0 && BM % RSTEP == 0 && RSTEP % 16 == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
     int a_yx[AROWS], a_img[AROWS];
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RSTEP * i;
         a_img[i] = -1;
         a_yx[i] = 0;
         if (m < p.M) {
@@ -116,7 +129,9 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
     }
     const int sgn = (p.mode >= PFA_TCONV_S2) ? -1 : 1;
 
-    auto stage = [&](int ks, int buf) {
+    // ---- generic staging: every lane derives (tap, channel chunk) from its flattened chunk index each K-step.
+    //      Used when a K-step can span several taps (few channels: the 3/6-channel image layers).
+    auto stage_narrow = [&](int ks, int buf) {
         char* abase = smem + buf * STAGE;
         char* wbase = abase + A_BYTES;
         const int f = ks * 8 + g;
@@ -144,19 +159,84 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
             const bool ok = kval & (a_img[i] >= 0) & ((unsigned)y < (unsigned)p.hs) & ((unsigned)x < (unsigned)p.ws);
             const long long off = ((long long)(a_img[i] + y * p.ws + x) * csrc + cc) * (long long)sizeof(T);
             const char* gp = sbase + (ok ? off : zoff);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
         }
-        if (BN >= 32 || wave < 2) {
+        if (wave < WWAVES) {
             const long long zoffw = zero - p.w;
 #pragma unroll
             for (int i = 0; i < WROWS; ++i) {
-                const int n = n0 + r0 + 32 * i;
+                const int n = n0 + r0 + RSTEP * i;
                 const bool ok = kval & (n < p.n);
                 const long long off = ((long long)(n * 16 + widx) * p.ctot + c) * (long long)sizeof(T);
                 const char* gp = p.w + (ok ? off : zoffw);
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
             }
         }
+    };
+
+    // ---- wide staging (channel counts that are multiples of one K-step: every MFMA-heavy layer).
+    //      A K-step lies inside one (tap, source) segment, so the row pointers are rebuilt only when the
+    //      segment changes and otherwise just advance by 128 bytes: ~2 VALU ops per row per K-step.
+    const char* a_ptr[AROWS];
+    const char* w_ptr[WROWS];
+    int a_inc[AROWS], w_inc[WROWS];
+    int seg_tap = 0, seg_part = 0, seg_left = 0;
+    auto seg_setup = [&](int kc) {      // kc: K-step offset inside the segment (non-zero only for a split-K start)
+        int ty, tx, widx;
+        if (p.mode == PFA_TCONV_S2) {
+            ty = seg_tap >> 1; tx = seg_tap & 1;
+            widx = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+        } else {
+            ty = seg_tap >> 2; tx = seg_tap & 3;
+            widx = seg_tap;
+        }
+        const char* sbase = seg_part ? p.src2 : p.src1;
+        const int csrc = seg_part ? p.c2 : p.c1;
+        const int cc = (kc * 8 + g) * CH;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            const int y = (a_yx[i] >> 16) + sgn * ty;
+            const int x = (int)(short)(a_yx[i] & 0xffff) + sgn * tx;
+            const bool ok = (a_img[i] >= 0) & ((unsigned)y < (unsigned)p.hs) & ((unsigned)x < (unsigned)p.ws);
+            const long long off = ((long long)(a_img[i] + y * p.ws + x) * csrc + cc) * (long long)sizeof(T);
+            a_ptr[i] = ok ? sbase + off : zero;
+            a_inc[i] = ok ? 128 : 0;
+        }
+        const int cw = (seg_part ? p.c1 : 0) + cc;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int n = n0 + r0 + RSTEP * i;
+            const bool ok = n < p.n;
+            w_ptr[i] = ok ? p.w + ((long long)(n * 16 + widx) * p.ctot + cw) * (long long)sizeof(T) : zero;
+            w_inc[i] = ok ? 128 : 0;
+        }
+        seg_left = (seg_part ? p.spt - p.sp1 : p.sp1) - kc;
+    };
+    auto stage_wide = [&](int buf) {
+        char* abase = smem + buf * STAGE;
+        char* wbase = abase + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_ptr[i]), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
+            a_ptr[i] += a_inc[i];
+        }
+        if (wave < WWAVES) {
+#pragma unroll
+            for (int i = 0; i < WROWS; ++i) {
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_ptr[i]), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+                w_ptr[i] += w_inc[i];
+            }
+        }
+        if (--seg_left == 0) {          // next segment: the other source of this tap, or the next tap
+            if (seg_part == 0 && p.sp1 < p.spt) seg_part = 1;
+            else { seg_part = 0; ++seg_tap; }
+            seg_setup(0);               // (one harmless setup past the last tap: pointers are never used)
+        }
+    };
+    auto stage = [&](int ks, int buf) {
+        if (p.dbg & 8) return;
+        if (p.wide) stage_wide(buf);
+        else stage_narrow(ks, buf);
     };
 
     f32x4 acc[FN][FM];
@@ -167,6 +247,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
 
     const int lrow = lane & 15, kk = lane >> 4;
     auto compute = [&](int buf) {
+        if (p.dbg & 4) return;
         const char* abase = smem + buf * STAGE;
         const char* wbase = abase + A_BYTES;
 #pragma unroll
@@ -192,12 +273,38 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
 
     const int ks0 = split * p.kper;
     const int ks1 = min(p.ksteps, ks0 + p.kper);
-    if (ks0 < ks1) stage(ks0, 0);
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const int buf = (ks - ks0) & 1;
-        __syncthreads();              // waits vmcnt(0): stage ks has landed; everyone is done reading buf^1
-        if (ks + 1 < ks1) stage(ks + 1, buf ^ 1);
-        compute(buf);
+    if (p.wide) {
+        seg_tap = ks0 / p.spt;
+        const int within = ks0 - seg_tap * p.spt;
+        seg_part = within >= p.sp1 ? 1 : 0;
+        seg_setup(seg_part ? within - p.sp1 : within);
+    }
+    if constexpr (STAGES == 2) {
+        if (ks0 < ks1) stage(ks0, 0);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int buf = (ks - ks0) & 1;
+            __syncthreads();          // waits vmcnt(0): stage ks has landed; everyone is done reading buf^1
+            if (ks + 1 < ks1) stage(ks + 1, buf ^ 1);
+            compute(buf);
+        }
+    } else {
+        const int nks = ks1 - ks0;
+        if (nks > 0) stage(ks0, 0);
+        if (nks > 1) stage(ks0 + 1, 1);
+        int buf = 0;
+        for (int i = 0; i < nks; ++i) {
+            // retire step i's DMA but leave step i+1's in flight (this wave issued AROWS [+ WROWS] per step)
+            if (i + 1 < nks) {
+                if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
+                else PFA_WAIT_VMCNT(AROWS);
+            } else {
+                PFA_WAIT_VMCNT(0);
+            }
+            __builtin_amdgcn_s_barrier();   // every wave's step-i data is in LDS; everyone finished reading ring slot (i-1)%3
+            if (i + 2 < nks) stage(ks0 + i + 2, buf == 0 ? 2 : buf - 1);
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -246,7 +353,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
         }
     }
 
-    if (p.psum) {
+    if (p.psum && !(p.dbg & 2)) {
         // per-column sums over this tile's rows (rows >= M are exact zeros: their operands were the zero page,
         // and BatchNorm layers carry no bias)
         __syncthreads();
@@ -284,7 +391,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const GatherK p) {
         char* obase; int col, ld;
         if (nbase < p.n1) { obase = p.out1; col = nbase; ld = p.ld1; }
         else { obase = p.out2; col = nbase - p.n1; ld = p.ld2; }
-        if (col < ld) {
+        if (col < ld && !(p.dbg & 1)) {
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 if (!mval[b]) continue;
@@ -450,6 +557,11 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.kper = (k.ksteps + k.splitk - 1) / k.splitk;
     k.splitk = (k.ksteps + k.kper - 1) / k.kper;     // no empty slices
     k.act = a->act; k.slope = a->slope;
+    const int kstep_ch = 8 * ch;                  // channels per K-step
+    k.wide = (a->c1 % kstep_ch == 0 && a->c2 % kstep_ch == 0) ? 1 : 0;
+    k.spt = k.wide ? k.ctot / kstep_ch : 1;
+    k.sp1 = k.wide ? a->c1 / kstep_ch : 1;
+    k.dbg = g_knob[1];
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of splitk*pixels*round4(n) floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
@@ -461,8 +573,18 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     return 0;
 }
 
-inline int pick_bn(int n) { return n <= 16 ? 16 : (n <= 64 ? 64 : 128); }
-inline int bm_of(int bn) { return bn == 16 ? 256 : 128; }
+// ---- tile configuration
+// id 0: 128x128, 4 waves, 2 stages   id 1: 128x64, 4 waves, 2 stages   id 2: 256x16, 4 waves, 2 stages
+// id 3: 128x128, 4 waves, 3-stage ring   id 4: 256x128, 8 waves, 3-stage ring
+struct TileCfg { int id, bm, bn; };
+
+inline TileCfg choose_cfg(const GatherK& k) {
+    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 128, 128}, {4, 256, 128}};
+    if (k.n <= 16) return cfgs[2];
+    if (k.n <= 64) return cfgs[1];
+    if (g_knob[0] >= 1 && g_knob[0] <= 5 && cfgs[g_knob[0] - 1].bn == 128) return cfgs[g_knob[0] - 1];
+    return cfgs[0];
+}
 
 }  // namespace
 
@@ -473,25 +595,42 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
         const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act, k.npix);
         return (k.npix + rpb - 1) / rpb;
     }
-    const int bm = bm_of(pick_bn(k.n));
+    const int bm = choose_cfg(k).bm;
     return classes * ((k.M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.mtiles = (k.M + BM - 1) / BM;
     k.ntiles = (k.n + BN - 1) / BN;
     k.nwg = k.mtiles * k.ntiles * classes * k.splitk;
     dim3 grid(k.nwg);
-    const size_t lds = 2 * (BM * 128 + BN * 128);
+    const size_t lds = STAGES * (BM * 128 + BN * 128);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, STAGES>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), lds, st, k);
     PFA_LAUNCHED("k_gather_gemm");
+    return 0;
+}
+
+template <typename T>
+static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_gather<T, 128, 128, 2, 2, 2>(k, classes, st);
+        case 1: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
+        case 2: return launch_gather<T, 256, 16, 4, 1, 2>(k, classes, st);
+        case 3: return launch_gather<T, 128, 128, 2, 2, 3>(k, classes, st);
+        default: return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+    }
+}
+
+extern "C" int pfa_set_knob(int id, int value) {
+    PFA_REQUIRE(id >= 0 && id < 8, "pfa_set_knob: id out of range");
+    g_knob[id] = value;
     return 0;
 }
 
@@ -538,19 +677,12 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
     hipStream_t st = (hipStream_t)s;
-    const int bn = pick_bn(k.n);
+    const TileCfg cfg = choose_cfg(k);
     int rc;
     GatherK kk = k;
     if (k.splitk > 1) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
-    if (a->dtype == PFA_BF16) {
-        if (bn == 128) rc = launch_gather<bf16_t, 128, 128, 2, 2>(kk, classes, st);
-        else if (bn == 64) rc = launch_gather<bf16_t, 128, 64, 2, 2>(kk, classes, st);
-        else rc = launch_gather<bf16_t, 256, 16, 4, 1>(kk, classes, st);
-    } else {
-        if (bn == 128) rc = launch_gather<float, 128, 128, 2, 2>(kk, classes, st);
-        else if (bn == 64) rc = launch_gather<float, 128, 64, 2, 2>(kk, classes, st);
-        else rc = launch_gather<float, 256, 16, 4, 1>(kk, classes, st);
-    }
+    rc = a->dtype == PFA_BF16 ? dispatch_gather<bf16_t>(kk, classes, cfg.id, st)
+                              : dispatch_gather<float>(kk, classes, cfg.id, st);
     if (rc) return rc;
     if (k.splitk > 1) {
         int tiles = 0;
@@ -560,7 +692,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         if (rc) return rc;
         a->ntiles_stat = tiles;
     } else {
-        a->ntiles_stat = classes * ((k.M + bm_of(bn) - 1) / bm_of(bn));
+        a->ntiles_stat = classes * ((k.M + cfg.bm - 1) / cfg.bm);
     }
     return 0;
 }

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "pfa_version": (c_int, []),
     "pfa_last_error_string": (c_char_p, []),
     "pfa_launch_count": (c_uint64, []),
+    "pfa_set_knob": (c_int, [c_int, c_int]),
     "pfa_gather_stat_tiles": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_gemm": (c_int, [POINTER(GatherArgs), c_void_p]),
     "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
@@ -91,6 +92,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _LIB = handle
+        for item in filter(None, os.environ.get("PFA_KNOBS", "").split(",")):   # e.g. PFA_KNOBS=0=5 (A/B runs)
+            k, v = item.split("=")
+            handle.pfa_set_knob(int(k), int(v))
     return _LIB
 
 

@@ -244,16 +244,67 @@ class GanTrainer:
         return ld, lg
 
 
-def _trainer_for(gen, disc, opt_g, opt_d, precision=None):
+def _trainer_for(gen, disc, opt_g, opt_d, precision=None, process_group=None):
     tr = getattr(gen, "_pfa_trainer", None)
-    if tr is None or tr.disc is not disc or tr.opt_g is not opt_g or tr.opt_d is not opt_d \
+    if tr is None or tr.disc is not disc or tr.opt_g is not opt_g or tr.opt_d is not opt_d or tr.pg is not process_group \
             or not (tr.G.still_bound() and tr.Dn.still_bound()):
-        tr = GanTrainer(gen, disc, opt_g, opt_d, precision=precision or gen.precision)
+        tr = GanTrainer(gen, disc, opt_g, opt_d, precision=precision or gen.precision, process_group=process_group)
         object.__setattr__(gen, "_pfa_trainer", tr)
     return tr
 
 
-def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=LAMBDA_L1):
+# ----------------------------------------------------------------------------------- data parallel helpers
+def broadcast_model(module, process_group=None, src=0):
+    """Rank `src`'s parameters and buffers become every rank's (start of training / after a resume)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.is_contiguous():
+            torch.distributed.broadcast(t.data, src, group=process_group)
+        else:                                   # channels-last views into the flat arena
+            tmp = t.data.contiguous()
+            torch.distributed.broadcast(tmp, src, group=process_group)
+            t.data.copy_(tmp)
+
+
+def allreduce_mean_grads(module, process_group=None):
+    """Average .grad over the ranks with ONE collective per network (flat float32 buffer), the host-side form of
+    what GanTrainer does on its gradient arena.  Works on any backend (gloo on CPU, RCCL on GPU)."""
+    ps = [p for p in module.parameters() if p.grad is not None]
+    if not ps:
+        return
+    world = torch.distributed.get_world_size(process_group)
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    torch.distributed.all_reduce(flat, group=process_group)
+    flat.div_(world)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view(p.grad.shape))
+        off += n
+
+
+def load_training_state(ckpt_dir, gen, disc, opt_g, opt_d, device):
+    """Resume from the newest generator_epoch_N.pth (+ discriminator, + trainer_epoch_N.pt when present)."""
+    import glob
+    import os
+    import re
+    epochs = sorted(int(re.search(r"generator_epoch_(\d+)\.pth$", f).group(1))
+                    for f in glob.glob(os.path.join(ckpt_dir, "generator_epoch_*.pth")))
+    if not epochs:
+        raise FileNotFoundError(f"no generator_epoch_*.pth in {ckpt_dir}")
+    e = epochs[-1]
+    gen.load_state_dict(torch.load(os.path.join(ckpt_dir, f"generator_epoch_{e}.pth"), map_location=device))
+    disc.load_state_dict(torch.load(os.path.join(ckpt_dir, f"discriminator_epoch_{e}.pth"), map_location=device))
+    extra = os.path.join(ckpt_dir, f"trainer_epoch_{e}.pt")
+    if os.path.exists(extra):
+        st = torch.load(extra, map_location=device)
+        if isinstance(opt_g, FusedAdam):
+            gen.engine(), disc.engine()
+        opt_g.load_state_dict(st["opt_g"])
+        opt_d.load_state_dict(st["opt_d"])
+    return e
+
+
+def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=LAMBDA_L1, process_group=None):
     """Same contract as the reference's train_gan_one_epoch (train_gan.py:46-75): iterates `loader` (dict
     batches with "image1"/"image2"), returns (mean loss_d, mean loss_g).
 
@@ -266,7 +317,7 @@ def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=
     p = next(gen.parameters())
     device = p.device if device is None else device
     if p.is_cuda and isinstance(opt_g, FusedAdam) and isinstance(opt_d, FusedAdam):
-        tr = _trainer_for(gen, disc, opt_g, opt_d)
+        tr = _trainer_for(gen, disc, opt_g, opt_d, process_group=process_group)
         tr.lambda_l1 = float(lambda_l1)
         tr.epoch_losses(reset=True)
         for batch in loader:
@@ -288,12 +339,16 @@ def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=
         pf = disc(torch.cat((real_a, fake), 1))
         loss_d = (bce(pr, torch.ones_like(pr)) + bce(pf, torch.zeros_like(pf))) * 0.5
         loss_d.backward()
+        if process_group is not None:
+            allreduce_mean_grads(disc, process_group)
         opt_d.step()
         opt_g.zero_grad()
         fake = gen(real_a)
         pg = disc(torch.cat((real_a, fake), 1))
         loss_g = bce(pg, torch.ones_like(pg)) + l1(fake, real_b) * lambda_l1
         loss_g.backward()
+        if process_group is not None:
+            allreduce_mean_grads(gen, process_group)      # only G: D's .grad here is the wasted by-product
         opt_g.step()
         sum_d += loss_d.item()
         sum_g += loss_g.item()

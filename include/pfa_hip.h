@@ -50,6 +50,9 @@ const char* pfa_last_error_string(void);
 /* Number of kernel launches issued by this process through the library (tests use it to
  * prove the HIP path, not a fallback, produced a result). */
 uint64_t pfa_launch_count(void);
+/* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: force a gather tile
+ * configuration (1..5), 0 = automatic. */
+int pfa_set_knob(int id, int value);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA
  * out[pix(m)][n] = act( bias[n] + sum_{tap,c} src[pix(m)+tap][c] * w[n][tap][c] )

@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads and exports exactly what include/pfa_hip.h declares (no compute calls)."""
+import os
+import re
+
+from pfa_gan import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "pfa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(pfa_[a-z0-9_]+)\s*\(", text))
+
+
+def test_header_and_binding_agree():
+    assert declared_functions() == set(_lib.PROTOTYPES), "include/pfa_hip.h and pfa_gan/_lib.py list different entry points"
+
+
+def test_library_exports_every_symbol():
+    lib = _lib.lib()                      # raises if the .so is missing or a symbol cannot be bound
+    for name in declared_functions():
+        assert getattr(lib, name) is not None
+    assert lib.pfa_version() >= 100
+    assert lib.pfa_last_error_string() is not None
+    assert lib.pfa_launch_count() == 0 or lib.pfa_launch_count() > 0
+
+
+def test_argument_validation_needs_no_gpu():
+    a = _lib.GatherArgs()                 # struct_size 0 -> rejected before any HIP call
+    assert _lib.lib().pfa_gather_gemm(a, None) < 0
+    assert b"struct_size" in _lib.lib().pfa_last_error_string()
+    w = _lib.WgradArgs()
+    assert _lib.lib().pfa_wgrad(w, None) < 0
+
+
+def test_struct_layout_matches_the_header():
+    import ctypes
+    # 18 int32/float fields then 9 pointers; 16 x 4 + 2 x 4 = 72 bytes of scalars, 8-byte aligned pointers after
+    assert ctypes.sizeof(_lib.GatherArgs) == 72 + 9 * 8
+    assert ctypes.sizeof(_lib.WgradArgs) == 18 * 4 + 5 * 8

@@ -1,0 +1,163 @@
+"""CPU: host-side logic - module structure / checkpoint layout, the CPU plumbing run (BASELINE config 1),
+the data-parallel helpers on gloo (world_size 2), oracle schedule invariants."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pfa_gan
+from oracle import fill, nets, step as ostep
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "gan-aug-pfa_amd")
+
+
+def test_state_dict_manifest_matches_reference_layout():
+    """Appendix A of SURVEY.md: key order, shapes, dtypes of the default networks (70 / 22 entries)."""
+    G, D = pfa_gan.UNetGenerator(3, 3), pfa_gan.NLayerDiscriminator(6)
+    gs, ds = nets.g_state_shapes(), nets.d_state_shapes()
+    assert len(gs) == 70 and len(ds) == 22
+    for m, shapes in ((G, gs), (D, ds)):
+        sd = m.state_dict()
+        assert list(sd) == list(shapes)
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k])
+            assert v.dtype == (torch.int64 if k.endswith("num_batches_tracked") else torch.float32)
+    assert sum(p.numel() for p in G.parameters()) == 41_828_995
+    assert sum(p.numel() for p in D.parameters()) == 2_768_705
+    assert sum(p.numel() for p in pfa_gan.UNetGenerator(3, 3, num_downs=6).parameters()) == 29_244_035
+
+
+def test_cpu_modules_follow_the_oracle(golden):
+    """On a CPU tensor the drop-in modules execute plain PyTorch; same numbers as the reference goldens."""
+    z = golden("nets")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8)
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in fill.fill_state(nets.g_state_shapes(3, 3, 5, 8), seed=1).items()})
+    x = torch.from_numpy(fill.uniform("small.x", (2, 3, 32, 32), seed=int(z["small.g.seed"])))
+    np.testing.assert_allclose(G(x).detach().numpy(), z["small.g.y"], atol=1e-5, rtol=1e-4)
+    with pytest.raises(ValueError):
+        pfa_gan.UNetGenerator(3, 3, num_downs=4)
+
+
+def test_instance_norm_variant_keys():
+    """norm_layer=nn.InstanceNorm2d flips the conv biases on (models.py:171-174): 28 / 10 keys."""
+    import functools
+    G = pfa_gan.UNetGenerator(3, 3, norm_layer=torch.nn.InstanceNorm2d)
+    D = pfa_gan.NLayerDiscriminator(6, norm_layer=torch.nn.InstanceNorm2d)
+    assert len(G.state_dict()) == 28 and len(D.state_dict()) == 10
+    Ga = pfa_gan.UNetGenerator(3, 3, norm_layer=functools.partial(torch.nn.InstanceNorm2d, affine=True))
+    assert len(Ga.state_dict()) == 50
+
+
+def _write_pairs(root, n, size):
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    for i in range(n):
+        city = f"city{i}"
+        os.makedirs(os.path.join(root, "images", city, "pair"))
+        os.makedirs(os.path.join(root, "labels", city, "cm"))
+        for nm in ("img1", "img2"):
+            Image.fromarray(rng.randint(0, 256, (size, size, 3), dtype=np.uint8)).save(
+                os.path.join(root, "images", city, "pair", nm + ".png"))
+        Image.fromarray((rng.rand(size, size) > 0.7).astype(np.uint8) * 255).save(
+            os.path.join(root, "labels", city, "cm", "cm.png"))
+
+
+def test_baseline_config1_cpu_plumbing(tmp_path):
+    """BASELINE config 1: 4 synthetic 64x64 RGB pairs, batch 2, 1 epoch on PyTorch-CPU (num_downs=6: the default 7
+    cannot run 64x64) -> checkpoints in the reference layout, consumed by the generation script."""
+    root = str(tmp_path)
+    _write_pairs(root, 4, 64)
+    env = dict(os.environ, TQDM_DISABLE="1")
+    cmd = [sys.executable, os.path.join(PKG, "train_gan.py"), "--root", root, "--images-dir", os.path.join(root, "images"),
+           "--labels-dir", os.path.join(root, "labels"), "--device", "cpu", "--size", "64", "--num-downs", "6", "--ngf", "8",
+           "--ndf", "8", "--batch-size", "2", "--epochs", "1", "--workers", "0", "--seed", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Avg Loss D" in r.stdout
+    gpath = os.path.join(root, "gan_checkpoints", "generator_epoch_1.pth")
+    sd = torch.load(gpath)
+    assert list(sd) == list(nets.g_state_shapes(3, 3, 6, 8))
+    assert int(sd["model.model.1.model.2.num_batches_tracked"]) == 4      # 2 steps x 2 generator forwards
+    assert os.path.exists(os.path.join(root, "gan_checkpoints", "discriminator_epoch_1.pth"))
+    assert any(f.startswith("sample_") for f in os.listdir(os.path.join(root, "gan_samples")))
+    out = os.path.join(root, "synthetic_data")
+    cmd = [sys.executable, os.path.join(PKG, "generate_synthetic_data.py"), "--images-dir", os.path.join(root, "images"),
+           "--labels-dir", os.path.join(root, "labels"), "--checkpoint", gpath, "--out-dir", out, "--device", "cpu",
+           "--size", "64", "--num-downs", "6", "--ngf", "8", "--workers", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    from pfa_gan.data import scan_dataset
+    found = scan_dataset(os.path.join(out, "images"), os.path.join(out, "labels"), is_synthetic=True)
+    assert len(found) == 4 and all(s["city"].endswith("_synth") for s in found)
+
+
+def test_oracle_minimal_schedule_side_effects():
+    """F5 / Appendix B: one step leaves G's BN counters at +2 and D's at +3."""
+    gst = fill.fill_state(nets.g_state_shapes(3, 3, 5, 8), seed=5, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(6, 8, 3), seed=6, bn_noise=False)
+    a, b = fill.uniform("sched.a", (2, 3, 32, 32)), fill.uniform("sched.b", (2, 3, 32, 32))
+    ld, lg, _ = ostep.gan_step(gst, dst, ostep.new_adam_state(gst), ostep.new_adam_state(dst), a, b, 5, 3)
+    assert int(gst["model.model.1.model.2.num_batches_tracked"]) == 2
+    assert int(dst["model.3.num_batches_tracked"]) == 3
+    assert 0.6 < ld < 0.8 and 40 < lg < 80
+
+
+# ------------------------------------------------------------------------------ data parallel, gloo, 2 ranks
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                       # deliberately different initial weights per rank
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8)
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8)
+        pfa_gan.broadcast_model(G)
+        pfa_gan.broadcast_model(D)
+        og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        batches = [dict(image1=torch.from_numpy(fill.uniform(f"dp.a{i}", (2, 3, 32, 32), seed=rank)),
+                        image2=torch.from_numpy(fill.uniform(f"dp.b{i}", (2, 3, 32, 32), seed=rank))) for i in range(2)]
+        # gradient averaging itself, on known values
+        for p in G.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+        pfa_gan.allreduce_mean_grads(G, dist.group.WORLD)
+        assert all(torch.allclose(p.grad, torch.full_like(p, 1.5)) for p in G.parameters())
+        ld, lg = pfa_gan.train_gan_one_epoch(G, D, batches, og, od, process_group=dist.group.WORLD)
+        flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            torch.save(dict(same=bool(torch.equal(gathered[0], gathered[1])), ld=ld, lg=lg, flat=flat,
+                            bn=[b.clone() for b in G.buffers()]), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_gloo(tmp_path):
+    """Two ranks, different shards: after every optimizer step both replicas hold identical parameters (rank 0's
+    broadcast + averaged gradients), BN statistics stay per-replica, and the result is not the single-rank one."""
+    out = str(tmp_path / "dp.pt")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["same"], "replicas diverged"
+    assert np.isfinite(r["ld"]) and np.isfinite(r["lg"])
+    # single process on rank 0's shard only, same initial weights -> different result (the all-reduce mattered)
+    torch.manual_seed(100)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8)
+    D = pfa_gan.NLayerDiscriminator(6, ndf=8)
+    og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    batches = [dict(image1=torch.from_numpy(fill.uniform(f"dp.a{i}", (2, 3, 32, 32), seed=0)),
+                    image2=torch.from_numpy(fill.uniform(f"dp.b{i}", (2, 3, 32, 32), seed=0))) for i in range(2)]
+    pfa_gan.train_gan_one_epoch(G, D, batches, og, od)
+    flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+    assert not torch.equal(flat, r["flat"])
+    # per-replica BN statistics: rank 0 saw rank 0's shard only -> its running buffers equal the single-rank ones
+    # after the first forward would differ only through the weights; counters are exact
+    assert [int(b) for b in r["bn"] if b.dtype == torch.int64] == [int(b) for b in G.buffers() if b.dtype == torch.int64]
