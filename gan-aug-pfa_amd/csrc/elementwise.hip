@@ -25,6 +25,16 @@ inline int grid_for(int64_t work, int block = 256, int cap = 256 * 16) {
     return (int)g;
 }
 
+// grid for the per-channel elementwise kernels: total threads a multiple of cpr (chunks per row)
+inline int grid_chan(int64_t nchunks, int cpr, int cap = 256 * 8) {
+    int g = grid_for(nchunks, 256, cap);
+    if (cpr > 256) {                      // more than 256 chunks per row: make blocks * 256 a multiple of cpr
+        const int per = cpr / 256;
+        g = (g + per - 1) / per * per;
+    }
+    return g;
+}
+
 // ------------------------------------------------------------------ BatchNorm statistics
 // Block = 8 channels x 32 tile-lanes: the per-tile partials are summed in parallel (double), then one lane
 // per channel finishes.  Deterministic: fixed tile -> lane assignment and a fixed-order LDS tree.
@@ -95,18 +105,27 @@ __global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 
 // ------------------------------------------------------------------ normalise + dual activation
+// The grid is sized so that (threads in the grid) % (chunks per row) == 0: a lane then always lands on the same
+// channel chunk and keeps its scale/shift in registers for the whole grid-stride loop.
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_act(const T* __restrict__ raw, int64_t nchunks, int cpr,
                                                 const float* __restrict__ scale, const float* __restrict__ shift,
                                                 float slope, T* out_l, T* out_r) {
     constexpr int CH = ElemTraits<T>::CH;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(idx % cpr) * CH;
+    const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(first % cpr) * CH;
+    float sc[CH], sh[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) {
+        sc[e] = scale ? scale[c0 + e] : 1.f;
+        sh[e] = scale ? shift[c0 + e] : 0.f;
+    }
+    for (int64_t idx = first; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
         Chunk<T> x, l, r;
         x.load(raw + idx * CH);
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
-            const float y = scale ? x.v[e] * scale[c0 + e] + shift[c0 + e] : x.v[e];
+            const float y = x.v[e] * sc[e] + sh[e];
             l.v[e] = y >= 0.f ? y : y * slope;
             r.v[e] = y > 0.f ? y : 0.f;
         }
@@ -200,13 +219,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* dy, const T* __restrict__ raw, int64_t nchunks,
                                                       int cpr, int c, const float* __restrict__ coef, T* dr) {
     constexpr int CH = ElemTraits<T>::CH;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(idx % cpr) * CH;
+    const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(first % cpr) * CH;           // fixed per lane (grid sized as for k_bn_act)
+    float ka[CH], kb[CH], kc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { ka[e] = coef[c0 + e]; kb[e] = coef[c + c0 + e]; kc[e] = coef[2 * c + c0 + e]; }
+    for (int64_t idx = first; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
         Chunk<T> d, x, o;
         d.load(dy + idx * CH);
         x.load(raw + idx * CH);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) o.v[e] = coef[c0 + e] * d.v[e] + coef[c + c0 + e] * x.v[e] + coef[2 * c + c0 + e];
+        for (int e = 0; e < CH; ++e) o.v[e] = ka[e] * d.v[e] + kb[e] * x.v[e] + kc[e];
         o.store(dr + idx * CH);
     }
 }
@@ -401,6 +424,60 @@ __global__ __launch_bounds__(256) void k_shadow_tr(const float* __restrict__ mas
     }
 }
 
+// Batched form: one launch covers every layer of a network; a block finds its layer in the descriptor table.
+constexpr int SHADOW_ELEMS = 256 * 8;
+__device__ __forceinline__ int find_layer(const pfa_shadow_desc* d, int n, int blk, bool tr) {
+    int l = 0;
+    while (l + 1 < n && (tr ? d[l + 1].tr_blk0 : d[l + 1].same_blk0) <= blk) ++l;
+    return l;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_shadow_same_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
+    const int l = find_layer(descs, n, blockIdx.x, false);
+    const pfa_shadow_desc d = descs[l];
+    const int cr = d.c1r + d.c2r, cp_tot = d.c1p + d.c2p;
+    const int64_t total = (int64_t)d.rows * 16 * cp_tot;
+    const int64_t base = (int64_t)(blockIdx.x - d.same_blk0) * SHADOW_ELEMS;
+    T* same = (T*)d.same;
+#pragma unroll
+    for (int k = 0; k < SHADOW_ELEMS / 256; ++k) {
+        const int64_t idx = base + k * 256 + threadIdx.x;
+        if (idx >= total) break;
+        const int cp = (int)(idx % cp_tot);
+        const int64_t rt = idx / cp_tot;
+        const int c = real_channel(cp, d.c1r, d.c1p, d.c2r);
+        same[idx] = from_f32<T>(c >= 0 ? d.master[rt * cr + c] : 0.f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_shadow_tr_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
+    __shared__ float tile[32][33];
+    const int l = find_layer(descs, n, blockIdx.x, true);
+    const pfa_shadow_desc d = descs[l];
+    const int cr = d.c1r + d.c2r, cp_tot = d.c1p + d.c2p;
+    const int tc = (cp_tot + 31) / 32, tr_ = (d.rows_p + 31) / 32;
+    int lb = blockIdx.x - d.tr_blk0;
+    const int cp0 = (lb % tc) * 32; lb /= tc;
+    const int r0 = (lb % tr_) * 32;
+    const int tap = lb / tr_;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    T* trp = (T*)d.tr;
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, cp = cp0 + tx;
+        float v = 0.f;
+        if (r < d.rows && cp < cp_tot) {
+            const int c = real_channel(cp, d.c1r, d.c1p, d.c2r);
+            if (c >= 0) v = d.master[((size_t)r * 16 + tap) * cr + c];
+        }
+        tile[ty + 8 * k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        const int cp = cp0 + ty + 8 * k, r = r0 + tx;
+        if (cp < cp_tot && r < d.rows_p) trp[((size_t)cp * 16 + tap) * d.rows_p + r] = from_f32<T>(tile[tx][ty + 8 * k]);
+    }
+}
+
 // ------------------------------------------------------------------ NCHW float32 <-> NHWC T
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_nhwc(const float* __restrict__ src, int n, int c, int64_t hw, int cp,
@@ -458,11 +535,13 @@ extern "C" int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const
     PFA_REQUIRE(raw && rows > 0 && c > 0 && (out_l || out_r), "pfa_bn_act: bad arguments");
     PFA_REQUIRE(c % pfa_ch(dtype) == 0, "pfa_bn_act: c=%d not a multiple of %d", c, pfa_ch(dtype));
     const int cpr = c / pfa_ch(dtype);
+    PFA_REQUIRE(cpr <= 256 ? 256 % cpr == 0 : cpr % 256 == 0, "pfa_bn_act: c/%d = %d must divide or be a multiple of 256", pfa_ch(dtype), cpr);
     const int64_t nchunks = rows * cpr;
+    const int grid = grid_chan(nchunks, cpr);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(k_bn_act<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+               hipLaunchKernelGGL(k_bn_act<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s,
                                   (const bf16_t*)raw, nchunks, cpr, scale, shift, slope, (bf16_t*)out_l, (bf16_t*)out_r),
-               hipLaunchKernelGGL(k_bn_act<float>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+               hipLaunchKernelGGL(k_bn_act<float>, dim3(grid), dim3(256), 0, (hipStream_t)s,
                                   (const float*)raw, nchunks, cpr, scale, shift, slope, (float*)out_l, (float*)out_r));
     PFA_LAUNCHED("k_bn_act");
     return 0;
@@ -522,11 +601,13 @@ extern "C" int pfa_bn_bwd_apply(const void* dy, const void* raw, int64_t rows, i
     PFA_REQUIRE(dy && raw && coef && dr && rows > 0, "pfa_bn_bwd_apply: bad arguments");
     PFA_REQUIRE(c % pfa_ch(dtype) == 0, "pfa_bn_bwd_apply: c not a multiple of the chunk width");
     const int cpr = c / pfa_ch(dtype);
+    PFA_REQUIRE(cpr <= 256 ? 256 % cpr == 0 : cpr % 256 == 0, "pfa_bn_bwd_apply: unsupported channel count %d", c);
     const int64_t nchunks = rows * cpr;
+    const int grid = grid_chan(nchunks, cpr);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+               hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s,
                                   (const bf16_t*)dy, (const bf16_t*)raw, nchunks, cpr, c, coef, (bf16_t*)dr),
-               hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid_for(nchunks)), dim3(256), 0, (hipStream_t)s,
+               hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), 0, (hipStream_t)s,
                                   (const float*)dy, (const float*)raw, nchunks, cpr, c, coef, (float*)dr));
     PFA_LAUNCHED("k_bn_bwd_apply");
     return 0;
@@ -625,6 +706,28 @@ extern "C" int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p
                                       c2r, cp, rows_p, (float*)tr));
         PFA_LAUNCHED("k_shadow_tr");
     }
+    return 0;
+}
+
+extern "C" int pfa_shadow_blocks(int rows, int c1p, int c2p, int rows_p, int* same_blocks, int* tr_blocks) {
+    PFA_REQUIRE(rows > 0 && c1p > 0 && c2p >= 0 && rows_p >= rows && same_blocks && tr_blocks, "pfa_shadow_blocks: bad arguments");
+    const int cp = c1p + c2p;
+    *same_blocks = (int)(((int64_t)rows * 16 * cp + SHADOW_ELEMS - 1) / SHADOW_ELEMS);
+    *tr_blocks = ((cp + 31) / 32) * ((rows_p + 31) / 32) * 16;
+    return 0;
+}
+
+extern "C" int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int same_blocks, int tr_blocks,
+                                       int dtype, pfa_stream s) {
+    PFA_REQUIRE(descs_dev && n > 0 && same_blocks > 0 && tr_blocks > 0, "pfa_weight_shadow_batch: bad arguments");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_shadow_same_batch<bf16_t>, dim3(same_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
+               hipLaunchKernelGGL(k_shadow_same_batch<float>, dim3(same_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
+    PFA_LAUNCHED("k_shadow_same_batch");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_shadow_tr_batch<bf16_t>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
+               hipLaunchKernelGGL(k_shadow_tr_batch<float>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
+    PFA_LAUNCHED("k_shadow_tr_batch");
     return 0;
 }
 

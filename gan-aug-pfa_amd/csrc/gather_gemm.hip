@@ -250,24 +250,31 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         if (p.dbg & 4) return;
         const char* abase = smem + buf * STAGE;
         const char* wbase = abase + A_BYTES;
+        // all 2*(FN+FM) fragment reads of the K-step are issued up front: ds_reads retire in order, so the MFMAs
+        // start on counted lgkmcnt waits and the LDS latency is exposed once per K-step instead of once per group
+        typename Mma<T>::frag wf[2][FN], af[2][FM];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ch = kk + 4 * h;
-            typename Mma<T>::frag wf[FN], af[FM];
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 const int row = wn * TN + a * 16 + lrow;
-                wf[a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                wf[h][a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const int row = wm * TM + b * 16 + lrow;
-                af[b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                af[h][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[a], af[b], acc[a][b]);
+                for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[h][a], af[h][b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);  // first half runs on lgkmcnt(FN+FM): the second half's reads still in flight
         }
     };
 

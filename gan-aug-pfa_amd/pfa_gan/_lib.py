@@ -37,6 +37,12 @@ class WgradArgs(Structure):
     ]
 
 
+class ShadowDesc(Structure):
+    _fields_ = [("master", c_void_p), ("same", c_void_p), ("tr", c_void_p),
+                ("rows", c_int32), ("c1r", c_int32), ("c1p", c_int32), ("c2r", c_int32), ("c2p", c_int32),
+                ("rows_p", c_int32), ("same_blk0", c_int32), ("tr_blk0", c_int32)]
+
+
 # name -> (restype, argtypes); every symbol include/pfa_hip.h declares
 PROTOTYPES = {
     "pfa_version": (c_int, []),
@@ -67,6 +73,8 @@ PROTOTYPES = {
                          c_void_p, c_float, c_void_p]),
     "pfa_adam_tick": (c_int, [c_void_p, c_void_p]),
     "pfa_weight_shadow": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pfa_shadow_blocks": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "pfa_weight_shadow_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pfa_pack_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_unpack_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),

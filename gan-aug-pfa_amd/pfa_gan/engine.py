@@ -172,6 +172,7 @@ class _Engine:
         self.layers = []
         self._versions = None
         self._scratch = None
+        self._table = None
 
     def still_bound(self):
         return self.flat.bound() and getattr(self.module, "_pfa_flat", None) is self.flat
@@ -184,13 +185,34 @@ class _Engine:
             self._scratch = self.new_ctx()
         return self._scratch
 
+    def _shadow_table(self):
+        """Device-resident descriptor table so that ALL layers re-emit their shadows in two launches."""
+        import ctypes
+        from ._lib import ShadowDesc, lib
+        n = len(self.layers)
+        arr = (ShadowDesc * n)()
+        sb = tb = 0
+        for i, L in enumerate(self.layers):
+            (c1r, c1p), (c2r, c2p) = L.cparts[0], (L.cparts[1] if len(L.cparts) > 1 else (0, 0))
+            a, b = ctypes.c_int(0), ctypes.c_int(0)
+            K.check(lib().pfa_shadow_blocks(L.rows, c1p, c2p, L.rows_p, ctypes.byref(a), ctypes.byref(b)), "pfa_shadow_blocks")
+            arr[i] = ShadowDesc(self.flat.seg(self.flat.data, L.w).data_ptr(), L.same.data_ptr(), L.tr.data_ptr(),
+                                L.rows, c1r, c1p, c2r, c2p, L.rows_p, sb, tb)
+            sb += a.value
+            tb += b.value
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return host.to(self.device), n, sb, tb
+
     def refresh_shadows(self, force=False):
         """Re-emit the kernel-side weight copies when a master parameter changed (torch bumps
         Tensor._version on every in-place write; the fused trainer forces it after its own Adam)."""
         versions = tuple(L.w._version for L in self.layers)
         if force or versions != self._versions:
-            for L in self.layers:
-                L.refresh()
+            if self._table is None:
+                self._table = self._shadow_table()
+            tab, n, sb, tb = self._table
+            K.check(K.lib().pfa_weight_shadow_batch(tab.data_ptr(), n, sb, tb, K.dt_code(self.dtype), K.stream()),
+                    "pfa_weight_shadow_batch")
             self._versions = versions
 
     # BatchNorm plumbing ------------------------------------------------------------

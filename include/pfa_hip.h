@@ -178,6 +178,18 @@ int pfa_adam_tick(int32_t* step_dev, pfa_stream s);
  *   tr  : [c1p+c2p][16][rows_p] in `dtype` (rows of pad channels zero).   Either may be NULL. */
 int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p, int c2r, int c2p, int rows_p, int dtype,
                       void* same, void* tr, pfa_stream s);
+/* All layers of a network in two launches: a device-resident table of descriptors (same fields as above, plus the
+ * first block index of each layer in the two launches, from pfa_shadow_blocks; layers in ascending block order). */
+typedef struct pfa_shadow_desc {
+    const float* master;
+    void* same;
+    void* tr;
+    int32_t rows, c1r, c1p, c2r, c2p, rows_p;
+    int32_t same_blk0, tr_blk0;
+} pfa_shadow_desc;
+int pfa_shadow_blocks(int rows, int c1p, int c2p, int rows_p, int* same_blocks, int* tr_blocks);
+int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int same_blocks, int tr_blocks, int dtype,
+                            pfa_stream s);
 /* NCHW float32 [n][c][h][w] <-> NHWC `dtype` [n][h][w][cp] (cp >= c, pad lanes zero / ignored). */
 int pfa_pack_nhwc(const float* src, int n, int c, int h, int w, int cp, int dtype, void* dst, pfa_stream s);
 int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dtype, float* dst, pfa_stream s);
