@@ -18,9 +18,9 @@
 // 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 #include "pfa_common.h"
 
-namespace {
-
 int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits
+
+namespace {
 
 struct GatherK {
     const char* src1;
@@ -246,13 +246,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lrow = lane & 15, kk = lane >> 4;
-    auto compute = [&](int buf) {
+    // A K-step in three phases: (1) all 2*(FN+FM) fragment reads, (2) issue of the next tile's DMA (its address
+    // arithmetic runs under the LDS latency), (3) the MFMAs, which the DMA then overlaps.
+    typename Mma<T>::frag wf[2][FN], af[2][FM];
+    auto read_frags = [&](int buf) {
         if (p.dbg & 4) return;
         const char* abase = smem + buf * STAGE;
         const char* wbase = abase + A_BYTES;
-        // all 2*(FN+FM) fragment reads of the K-step are issued up front: ds_reads retire in order, so the MFMAs
-        // start on counted lgkmcnt waits and the LDS latency is exposed once per K-step instead of once per group
-        typename Mma<T>::frag wf[2][FN], af[2][FM];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ch = kk + 4 * h;
@@ -267,14 +267,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
                 af[h][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
             }
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of the MFMAs (the scheduler sinks them otherwise)
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead (the scheduler sinks them otherwise)
+    };
+    auto mfma_frags = [&]() {
+        if (p.dbg & 4) return;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int a = 0; a < FN; ++a)
 #pragma unroll
                 for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[h][a], af[h][b], acc[a][b]);
-            __builtin_amdgcn_sched_barrier(0);  // first half runs on lgkmcnt(FN+FM): the second half's reads still in flight
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -291,8 +295,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         for (int ks = ks0; ks < ks1; ++ks) {
             const int buf = (ks - ks0) & 1;
             __syncthreads();          // waits vmcnt(0): stage ks has landed; everyone is done reading buf^1
+            read_frags(buf);
             if (ks + 1 < ks1) stage(ks + 1, buf ^ 1);
-            compute(buf);
+            mfma_frags();
         }
     } else {
         const int nks = ks1 - ks0;
@@ -308,8 +313,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
                 PFA_WAIT_VMCNT(0);
             }
             __builtin_amdgcn_s_barrier();   // every wave's step-i data is in LDS; everyone finished reading ring slot (i-1)%3
+            read_frags(buf);
             if (i + 2 < nks) stage(ks0 + i + 2, buf == 0 ? 2 : buf - 1);
-            compute(buf);
+            mfma_frags();
             buf = buf == 2 ? 0 : buf + 1;
         }
     }

@@ -17,6 +17,8 @@
 // The reduction is sliced over blockIdx.z; slices combine with float32 atomics (dw is pre-zeroed).
 #include "pfa_common.h"
 
+extern int g_knob[8];
+
 namespace {
 
 struct WgradK {
@@ -30,8 +32,12 @@ struct WgradK {
     int g1p, g1r, g2p, g2r, gp, gr;
     int M, mper;
     unsigned magic_hw, magic_wq;
+    int step_img, step_row, step_col;   // KM pixels = step_img images + step_row rows + step_col columns
     int jtot;        // 16 * gp
     int jtiles, itiles, nwg;
+    int dbg;         // ablation bits (pfa_set_knob 1): 1 no atomics, 4 no MFMA, 8 no DMA
+    float* slab;     // optional [msplit][tiles][BI*128] partial tiles (deterministic combine instead of atomics)
+    int msplit;
 };
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
@@ -101,8 +107,19 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         }
     }
     const int hw = p.hq * p.wq;
+    // pixel coordinates of this thread's gathered rows, advanced incrementally by KM pixels per step
+    int g_ni[GIT], g_qy[GIT], g_qx[GIT];
+#pragma unroll
+    for (int i = 0; i < GIT; ++i) {
+        const int mg = mbeg + i * (256 / RCG) + g_r0;
+        g_ni[i] = fastdiv(mg, hw, p.magic_hw);
+        const int rem = mg - g_ni[i] * hw;
+        g_qy[i] = fastdiv(rem, p.wq, p.magic_wq);
+        g_qx[i] = rem - g_qy[i] * p.wq;
+    }
 
     auto stage = [&](int mstep, int buf) {
+        if (p.dbg & 8) return;
         char* dbase = smem + buf * STAGE;
         char* gbase = dbase + D_BYTES;
         if (d_active) {
@@ -117,16 +134,16 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
 #pragma unroll
         for (int i = 0; i < GIT; ++i) {
             const int mg = mstep + i * (256 / RCG) + g_r0;
-            bool ok = g_base && mg < mend;
-            const char* gp = zero;
-            if (ok) {
-                const int ni = fastdiv(mg, hw, p.magic_hw), rem = mg - ni * hw;
-                const int qy = fastdiv(rem, p.wq, p.magic_wq), qx = rem - qy * p.wq;
-                const int y = qy * p.stride - 1 + g_ky, x = qx * p.stride - 1 + g_kx;
-                if ((unsigned)y < (unsigned)p.hg && (unsigned)x < (unsigned)p.wg)
-                    gp = g_base + ((size_t)(ni * p.hg + y) * p.wg + x) * g_ld * sizeof(T);
-            }
+            const int y = g_qy[i] * p.stride - 1 + g_ky, x = g_qx[i] * p.stride - 1 + g_kx;
+            const bool ok = (g_base != nullptr) & (mg < mend) & ((unsigned)y < (unsigned)p.hg) & ((unsigned)x < (unsigned)p.wg);
+            const char* gp = ok ? g_base + ((size_t)(g_ni[i] * p.hg + y) * p.wg + x) * g_ld * sizeof(T) : zero;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(gbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            // advance by KM pixels: at most one carry per level (step_col < wq, step_row < hq)
+            g_qx[i] += p.step_col;
+            if (g_qx[i] >= p.wq) { g_qx[i] -= p.wq; ++g_qy[i]; }
+            g_qy[i] += p.step_row;
+            if (g_qy[i] >= p.hq) { g_qy[i] -= p.hq; ++g_ni[i]; }
+            g_ni[i] += p.step_img;
         }
     };
 
@@ -137,75 +154,107 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
         for (int b = 0; b < FJ; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int l15 = lane & 15, kk = lane >> 4;
-    auto compute = [&](int buf) {
+    bf16x8 af[2][FI], bfr[2][FJ];           // bf16 path: the fragments of one reduction step
+    // Phase 1 of a step: every LDS (transpose) read.  hipcc drains vmcnt before LDS reads that may alias an
+    // LDS-DMA in flight, so the NEXT tile's DMA is issued only after these reads (phase 2) and then runs under
+    // the MFMAs (phase 3) instead of in front of them.
+    auto read_frags = [&](int buf) {
+        if (p.dbg & 4) return;
         const char* dbase = smem + buf * STAGE;
         const char* gbase = dbase + D_BYTES;
-        if constexpr (BF) {
 #pragma unroll
-            for (int k32 = 0; k32 < 2; ++k32) {
-                bf16x8 af[FI], bfr[FJ];
+        for (int k32 = 0; k32 < 2; ++k32) {
 #pragma unroll
-                for (int e2 = 0; e2 < 2; ++e2) {
-                    // 4 pixels x 16 channels block per 16-lane group, delivered channel-major
-                    const int m = 32 * k32 + 8 * kk + 4 * e2 + (l15 >> 2);
-#pragma unroll
-                    for (int a = 0; a < FI; ++a) {
-                        const int col = wi * TI + a * 16 + 4 * (lane & 3);
-                        const int off = m * DROWB + (((col >> 3) ^ swz(m, RCD)) << 4) + ((col >> 2) & 1) * 8;
-                        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(dbase + off));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) af[a][4 * e2 + e] = t[e];
-                    }
-#pragma unroll
-                    for (int b = 0; b < FJ; ++b) {
-                        const int col = wj * TJ + b * 16 + 4 * (lane & 3);
-                        const int off = m * GROWB + (((col >> 3) ^ swz(m, RCG)) << 4) + ((col >> 2) & 1) * 8;
-                        bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (__attribute__((address_space(3))) bf16x4*)(gbase + off));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) bfr[b][4 * e2 + e] = t[e];
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < FI; ++a)
-#pragma unroll
-                    for (int b = 0; b < FJ; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int k4 = 0; k4 < KM / 4; ++k4) {
-                const int m = 4 * k4 + kk;
-                float af[FI], bfr[FJ];
+            for (int e2 = 0; e2 < 2; ++e2) {
+                // 4 pixels x 16 channels block per 16-lane group, delivered channel-major
+                const int m = 32 * k32 + 8 * kk + 4 * e2 + (l15 >> 2);
 #pragma unroll
                 for (int a = 0; a < FI; ++a) {
-                    const int col = wi * TI + a * 16 + l15;
-                    af[a] = *(const float*)(dbase + m * DROWB + (((col >> 2) ^ swz(m, RCD)) << 4) + (col & 3) * 4);
+                    const int col = wi * TI + a * 16 + 4 * (lane & 3);
+                    const int off = m * DROWB + (((col >> 3) ^ swz(m, RCD)) << 4) + ((col >> 2) & 1) * 8;
+                    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(dbase + off));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) af[k32][a][4 * e2 + e] = t[e];
                 }
 #pragma unroll
                 for (int b = 0; b < FJ; ++b) {
-                    const int col = wj * TJ + b * 16 + l15;
-                    bfr[b] = *(const float*)(gbase + m * GROWB + (((col >> 2) ^ swz(m, RCG)) << 4) + (col & 3) * 4);
+                    const int col = wj * TJ + b * 16 + 4 * (lane & 3);
+                    const int off = m * GROWB + (((col >> 3) ^ swz(m, RCG)) << 4) + ((col >> 2) & 1) * 8;
+                    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                        (__attribute__((address_space(3))) bf16x4*)(gbase + off));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bfr[k32][b][4 * e2 + e] = t[e];
                 }
-#pragma unroll
-                for (int a = 0; a < FI; ++a)
-#pragma unroll
-                    for (int b = 0; b < FJ; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_frags = [&]() {
+        if (p.dbg & 4) return;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k32 = 0; k32 < 2; ++k32) {
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[k32][a], bfr[k32][b], acc[a][b], 0, 0, 0);
+        }
+    };
+    auto compute_f32 = [&](int buf) {
+        if (p.dbg & 4) return;
+        const char* dbase = smem + buf * STAGE;
+        const char* gbase = dbase + D_BYTES;
+#pragma unroll
+        for (int k4 = 0; k4 < KM / 4; ++k4) {
+            const int m = 4 * k4 + kk;
+            float a32[FI], b32[FJ];
+#pragma unroll
+            for (int a = 0; a < FI; ++a) {
+                const int col = wi * TI + a * 16 + l15;
+                a32[a] = *(const float*)(dbase + m * DROWB + (((col >> 2) ^ swz(m, RCD)) << 4) + (col & 3) * 4);
+            }
+#pragma unroll
+            for (int b = 0; b < FJ; ++b) {
+                const int col = wj * TJ + b * 16 + l15;
+                b32[b] = *(const float*)(gbase + m * GROWB + (((col >> 2) ^ swz(m, RCG)) << 4) + (col & 3) * 4);
+            }
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a32[a], b32[b], acc[a][b], 0, 0, 0);
         }
     };
 
     if (mbeg < mend) stage(mbeg, 0);
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += KM) {
-        __syncthreads();
-        if (ms + KM < mend) stage(ms + KM, buf ^ 1);
-        compute(buf);
+        __syncthreads();              // tile `ms` has landed; everyone is done with the other buffer
+        if constexpr (BF) {
+            read_frags(buf);
+            if (ms + KM < mend) stage(ms + KM, buf ^ 1);
+            mfma_frags();
+        } else {
+            if (ms + KM < mend) stage(ms + KM, buf ^ 1);
+            compute_f32(buf);
+        }
         buf ^= 1;
     }
 
+    if (p.dbg & 1) return;
+    if (p.slab) {
+        // partial tile in accumulator order: element ((a*FJ+b)*4+r)*256 + tid -> 256-byte coalesced plain stores
+        float* dst = p.slab + ((size_t)wid * (p.itiles * p.jtiles) + (size_t)it * p.jtiles + jt) * (BI * BJ) + tid;
+#pragma unroll
+        for (int a = 0; a < FI; ++a)
+#pragma unroll
+            for (int b = 0; b < FJ; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[((a * FJ + b) * 4 + r) * 256] = acc[a][b][r];
+        return;
+    }
     // ---- epilogue: lane holds D[i = .. + 4*kk + r][j = .. + l15]; scatter-add into the master layout
 #pragma unroll
     for (int b = 0; b < FJ; ++b) {
@@ -230,6 +279,45 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     }
 }
 
+// dw[i][tap][c] += sum over slices of the slab tiles.  One thread per tile element and slice group (blockIdx.y);
+// within a group the slices are summed in a fixed order with 8 independent partial sums (loads stay in flight);
+// groups (only used when there are many slices) combine with one float atomic each - with a single group
+// (msplit <= 64) the result is bitwise reproducible.
+constexpr int RED_GROUP = 64;
+template <int BI, int WI, int WJ>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
+    constexpr int BJ = 128, TI = BI / WI, TJ = BJ / WJ, FJ = TJ / 16;
+    const int tile = blockIdx.x / (BI * BJ / 256);
+    const int e = (blockIdx.x % (BI * BJ / 256)) * 256 + threadIdx.x;
+    const int tid = e & 255, q = e >> 8, r = q & 3, ab = q >> 2, b = ab % FJ, a = ab / FJ;
+    const int lane = tid & 63, wave = tid >> 6, wi = wave % WI, wj = wave / WI;
+    const int jt = tile % p.jtiles, it = tile / p.jtiles;
+    const int ip = it * BI + wi * TI + a * 16 + 4 * (lane >> 4) + r;
+    const int j = jt * BJ + wj * TJ + b * 16 + (lane & 15);
+    if (j >= p.jtot) return;
+    const int tap = j / p.gp, cp = j - tap * p.gp;
+    int creal, ireal;
+    if (cp < p.g1p) creal = cp < p.g1r ? cp : -1;
+    else creal = (cp - p.g1p) < p.g2r ? p.g1r + cp - p.g1p : -1;
+    if (ip < p.d1p) ireal = ip < p.d1r ? ip : -1;
+    else ireal = (ip - p.d1p) < p.d2r ? p.d1r + ip - p.d1p : -1;
+    if (creal < 0 || ireal < 0) return;
+    const size_t stride = (size_t)p.itiles * p.jtiles * (BI * BJ);
+    const int k0 = blockIdx.y * RED_GROUP, k1 = min(p.msplit, k0 + RED_GROUP);
+    const float* src = p.slab + (size_t)tile * (BI * BJ) + e + (size_t)k0 * stride;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = k0;
+    for (; k + 8 <= k1; k += 8, src += 8 * stride) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += src[(size_t)u * stride];
+    }
+    for (int u = 0; k < k1; ++k, ++u, src += stride) s[u] += *src;
+    const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    float* dst = p.dw + ((size_t)ireal * 16 + tap) * p.gr + creal;
+    if (gridDim.y == 1) *dst += tot;
+    else atomicAdd(dst, tot);
+}
+
 template <typename T, int BI, int WI, int WJ>
 int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
     constexpr int KM = sizeof(T) == 2 ? 64 : 32;
@@ -244,14 +332,20 @@ int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
                                   (int)lds);
         attr_done = true;
     }
+    k.msplit = msplit;
     hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ>), grid, dim3(256), lds, st, k);
     PFA_LAUNCHED("k_wgrad");
+    if (k.slab) {
+        hipLaunchKernelGGL((k_wgrad_reduce<BI, WI, WJ>),
+                           dim3(k.jtiles * k.itiles * (BI * 128 / 256), (msplit + RED_GROUP - 1) / RED_GROUP), dim3(256), 0, st, k);
+        PFA_LAUNCHED("k_wgrad_reduce");
+    }
     return 0;
 }
 
 }  // namespace
 
-extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
+static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& small_i) {
     PFA_REQUIRE(a && a->struct_size == (int)sizeof(pfa_wgrad_args), "pfa_wgrad: bad struct_size");
     PFA_REQUIRE(a->dtype == PFA_F32 || a->dtype == PFA_BF16, "pfa_wgrad: bad dtype");
     const int ch = pfa_ch(a->dtype);
@@ -265,9 +359,9 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     PFA_REQUIRE(a->hg == (a->hq - 1) * a->stride + 2 && a->wg == (a->wq - 1) * a->stride + 2,
                 "pfa_wgrad: gathered size %dx%d inconsistent with direct %dx%d at stride %d", a->hg, a->wg, a->hq,
                 a->wq, a->stride);
-    WgradK k;
     k.dir1 = (const char*)a->dir1; k.dir2 = (const char*)a->dir2;
     k.gat1 = (const char*)a->gat1; k.gat2 = (const char*)a->gat2; k.dw = a->dw;
+    k.slab = a->slab;
     k.stride = a->stride; k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hg = a->hg; k.wg = a->wg;
     k.d1p = a->d1p; k.d1r = a->d1r; k.d2p = a->d2p; k.d2r = a->d2r; k.dp = a->d1p + a->d2p;
     k.g1p = a->g1p; k.g1r = a->g1r; k.g2p = a->g2p; k.g2r = a->g2r; k.gp = a->g1p + a->g2p; k.gr = a->g1r + a->g2r;
@@ -277,16 +371,34 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     k.magic_wq = (unsigned)(0x100000000ull / (unsigned)a->wq);
     if (hw == 1) k.magic_hw = 0xffffffffu;
     if (a->wq == 1) k.magic_wq = 0xffffffffu;
+    k.dbg = g_knob[1];
     k.jtot = 16 * k.gp;
     const int km = a->dtype == PFA_BF16 ? 64 : 32;
-    int msplit = a->msplit < 1 ? 1 : a->msplit;
+    k.step_img = km / hw;
+    k.step_row = (km % hw) / a->wq;
+    k.step_col = (km % hw) % a->wq;
+    msplit = a->msplit < 1 ? 1 : a->msplit;
     int steps = (k.M + km - 1) / km;
     if (msplit > steps) msplit = steps;
     int sper = (steps + msplit - 1) / msplit;
     msplit = (steps + sper - 1) / sper;
     k.mper = sper * km;
+    small_i = k.dp <= 16;
+    return 0;
+}
+
+extern "C" size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a) {
+    WgradK k; int msplit; bool small_i;
+    if (wgrad_setup(a, k, msplit, small_i)) return 0;
+    const int bi = small_i ? 16 : 128;
+    return (size_t)msplit * ((k.jtot + 127) / 128) * ((k.dp + bi - 1) / bi) * bi * 128;
+}
+
+extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
+    WgradK k; int msplit; bool small_i;
+    if (int rc = wgrad_setup(a, k, msplit, small_i)) return rc;
     hipStream_t st = (hipStream_t)s;
-    const bool small_i = k.dp <= 16;
+
     if (a->dtype == PFA_BF16)
         return small_i ? launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st) : launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st);
     return small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);

@@ -34,6 +34,7 @@ class WgradArgs(Structure):
         ("g1p", c_int32), ("g1r", c_int32), ("g2p", c_int32), ("g2r", c_int32),
         ("msplit", c_int32), ("reserved", c_int32),
         ("dir1", c_void_p), ("dir2", c_void_p), ("gat1", c_void_p), ("gat2", c_void_p), ("dw", c_void_p),
+        ("slab", c_void_p),
     ]
 
 
@@ -54,6 +55,7 @@ PROTOTYPES = {
     "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pfa_wgrad": (c_int, [POINTER(WgradArgs), c_void_p]),
+    "pfa_wgrad_slab_floats": (c_size_t, [POINTER(WgradArgs)]),
     "pfa_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_eval_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

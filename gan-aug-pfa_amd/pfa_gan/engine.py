@@ -340,7 +340,7 @@ class GeneratorEngine(_Engine):
                 raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
                 d = self._bn_backward(L, ctx, f"u{k}", raw, B * 4 * h * w, garena, g_up[k], K.ACT_RELU)
             srcs = [v["aR"][k]] if k == D - 1 else [v["aR"][k], v["uR"][k + 1]]
-            K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout])
+            K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=self.ws)
             if L.b is not None:
                 K.colsum(d, L.db(garena), self.ws, c_out=L.cout)
             g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
@@ -363,7 +363,7 @@ class GeneratorEngine(_Engine):
                 dr = self._bn_backward(L, ctx, f"e{k}", raw, B * h * w, garena, g_down, K.ACT_LRELU, g_skip[k],
                                        K.ACT_RELU)
             src = v["x"] if k == 0 else v["aL"][k - 1]
-            K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real)
+            K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=self.ws)
             if L.b is not None:
                 K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
             if k > 0:
@@ -454,7 +454,7 @@ class DiscriminatorEngine(_Engine):
                                        param_grads=param_grads)
             inputs = v["srcs"] if i == 0 else [v["a"][i - 1]]
             if param_grads:
-                K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real)
+                K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=self.ws)
                 if L.b is not None:
                     K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
             if i > 0 or need_dx:

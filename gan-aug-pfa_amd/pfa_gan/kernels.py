@@ -117,12 +117,19 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     return (psum, psq, a.ntiles_stat) if stats else None
 
 
-def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None):
+FORCE_SLAB = object()     # pass as ws= to force the slab combine whatever the slice count (tests)
+_FORCE_WS = None
+
+
+def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None):
     """dw[i][tap][c] += sum_m direct[m][i] * gathered[pix(m)+tap][c] (float32, atomically accumulated).
 
     direct/gathered: lists of 1-2 NHWC tensors; dreal/greal: real channel counts per part.
     """
     _require_cuda(*direct, *gathered, dw)
+    global _FORCE_WS
+    if ws is FORCE_SLAB and _FORCE_WS is None:
+        _FORCE_WS = Workspace(dw.device)
     a = WgradArgs()
     a.struct_size = ctypes.sizeof(WgradArgs)
     a.dtype, a.stride = dt_code(direct[0].dtype), stride
@@ -142,6 +149,10 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None):
     a.dir1, a.dir2 = ptr(direct[0]), ptr(direct[1]) if len(direct) > 1 else None
     a.gat1, a.gat2 = ptr(gathered[0]), ptr(gathered[1]) if len(gathered) > 1 else None
     a.dw = ptr(dw)
+    if ws is not None and (msplit >= 8 or ws is FORCE_SLAB):
+        # many reduction slices over a small dw: per-slice slabs + an ordered reduce beat ~1.3 TB/s float atomics
+        # (and are reproducible); with a few slices over a large dw the atomics are as fast and need no workspace
+        a.slab = ptr((ws if ws is not FORCE_SLAB else _FORCE_WS).get("wgslab", lib().pfa_wgrad_slab_floats(ctypes.byref(a))))
     check(lib().pfa_wgrad(ctypes.byref(a), stream()), "pfa_wgrad")
 
 

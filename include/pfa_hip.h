@@ -115,8 +115,11 @@ typedef struct pfa_wgrad_args {
     const void* dir2;
     const void* gat1;
     const void* gat2;
-    float* dw;                   /* [d1r+d2r][16][g1r+g2r], must be zeroed by the caller       */
+    float* dw;                   /* [d1r+d2r][16][g1r+g2r]; the result is ADDED to it (zero_grad semantics)   */
+    float* slab;                 /* optional workspace of pfa_wgrad_slab_floats(a) floats: reduction slices are  */
+                                 /* combined in a fixed order (bitwise reproducible) instead of float atomics   */
 } pfa_wgrad_args;
+size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a);
 int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s);
 
 /* ------------------------------------------------------------------ BatchNorm2d (training)

@@ -199,11 +199,18 @@ def test_conv_wgrad(case, dtype, ws):
     for c in cins:
         srcs.append(to_nhwc(x[:, o:o + c], dtype))
         o += c
-    dw = torch.zeros((co, 16, ci), dtype=torch.float32, device="cuda")
-    K.wgrad([to_nhwc(dy, dtype)], srcs, dw, stride, [co], cins, msplit=msplit)
+    dyt = to_nhwc(dy, dtype)
+    for use_ws in (None, K.FORCE_SLAB):        # float-atomic combine, then the deterministic slab combine
+        dw = torch.zeros((co, 16, ci), dtype=torch.float32, device="cuda")
+        K.wgrad([dyt], srcs, dw, stride, [co], cins, msplit=msplit, ws=use_ws)
+        torch.cuda.synchronize()
+        got = dw.cpu().numpy().reshape(co, 4, 4, ci).transpose(0, 3, 1, 2)
+        close(got, want, torch.float32, name)  # float32 accumulation of exact products in both modes
+    dw2 = torch.zeros_like(dw)
+    K.wgrad([dyt], srcs, dw2, stride, [co], cins, msplit=msplit, ws=K.FORCE_SLAB)
+    K.wgrad([dyt], srcs, dw2, stride, [co], cins, msplit=msplit, ws=K.FORCE_SLAB)     # accumulates (zero_grad semantics)
     torch.cuda.synchronize()
-    got = dw.cpu().numpy().reshape(co, 4, 4, ci).transpose(0, 3, 1, 2)
-    close(got, want, torch.float32, name)      # float32 accumulation of exact products in both modes
+    assert torch.equal(dw2, dw + dw), "slab combine must be bitwise reproducible and accumulate into dw"
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
@@ -221,11 +228,12 @@ def test_convT_wgrad(case, dtype, ws):
     for c in cins:
         srcs.append(to_nhwc(x[:, o:o + c], dtype))
         o += c
-    dw = torch.zeros((ci, 16, co), dtype=torch.float32, device="cuda")
-    K.wgrad(srcs, [to_nhwc(dy, dtype)], dw, 2, cins, [co])
-    torch.cuda.synchronize()
-    got = dw.cpu().numpy().reshape(ci, 4, 4, co).transpose(0, 3, 1, 2)
-    close(got, want, torch.float32, name)
+    for use_ws in (None, K.FORCE_SLAB):
+        dw = torch.zeros((ci, 16, co), dtype=torch.float32, device="cuda")
+        K.wgrad(srcs, [to_nhwc(dy, dtype)], dw, 2, cins, [co], ws=use_ws)
+        torch.cuda.synchronize()
+        got = dw.cpu().numpy().reshape(ci, 4, 4, co).transpose(0, 3, 1, 2)
+        close(got, want, torch.float32, name)
 
 
 # ---------------------------------------------------------------------------- BatchNorm, losses, Adam
