@@ -37,7 +37,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="img-pairs per GPU (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying hipGraphs")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as three captured hipGraphs (default: eager launches on two HIP streams, which "
+                         "measured faster: the graph executor does not run the forked side-stream branch concurrently)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
+    ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -136,7 +140,8 @@ def main():
     torch.manual_seed(0)                             # identical default init on every rank (reference init, a12)
     gen = pfa_gan.UNetGenerator(3, 3).cuda()
     disc = pfa_gan.NLayerDiscriminator(6).cuda()
-    trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph=not args.no_graph)
+    trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph=args.graph,
+                                 overlap=not args.no_overlap)
     if world > 1:                                    # rank 0's parameters and buffers are the job's
         for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
             torch.distributed.broadcast(t, 0)
@@ -185,7 +190,8 @@ def main():
             "config": {"workload": f"{args.size}x{args.size} RGB Pix2Pix G+D step (UNetGenerator num_downs=7 ngf=64 + "
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph x3 segments",
+                       "launch": "hipGraph x3 segments" if args.graph else
+                                 ("eager, 2 HIP streams" if not args.no_overlap else "eager, 1 HIP stream"),
                        "last_losses": [round(l, 4) for l in losses]},
         }
         if flop_pair:

@@ -169,6 +169,7 @@ class _Engine:
         self.flat = flat_of(module)
         self.device = self.flat.device
         self.ws = K.Workspace(self.device)
+        self.ws_side = K.Workspace(self.device)
         self.layers = []
         self._versions = None
         self._scratch = None
@@ -176,6 +177,18 @@ class _Engine:
 
     def still_bound(self):
         return self.flat.bound() and getattr(self.module, "_pfa_flat", None) is self.flat
+
+    def _param_grads(self, side, fn):
+        """Run a layer's parameter-gradient launches (wgrad, bias column sums).  They depend only on the layer's
+        output gradient, so with a side stream they run concurrently with the dgrad / BatchNorm chain on the main
+        stream (fork here; the caller joins before the optimizer).  Their workspace is not shared with the main
+        stream's kernels."""
+        if side is None:
+            fn(self.ws)
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn(self.ws_side)
 
     def new_ctx(self):
         return Ctx(self.device)
@@ -323,8 +336,9 @@ class GeneratorEngine(_Engine):
         ctx.v["fake"] = fake
         return fake
 
-    def backward(self, ctx, dpre, garena):
-        """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena."""
+    def backward(self, ctx, dpre, garena, side=None):
+        """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena.
+        side: optional second stream for the parameter-gradient kernels (join it before using garena)."""
         if not ctx.v.get("train", False):
             raise PfaError("generator backward needs a training-mode forward")
         D, dt = self.D, self.dtype
@@ -340,9 +354,11 @@ class GeneratorEngine(_Engine):
                 raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
                 d = self._bn_backward(L, ctx, f"u{k}", raw, B * 4 * h * w, garena, g_up[k], K.ACT_RELU)
             srcs = [v["aR"][k]] if k == D - 1 else [v["aR"][k], v["uR"][k + 1]]
-            K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=self.ws)
-            if L.b is not None:
-                K.colsum(d, L.db(garena), self.ws, c_out=L.cout)
+            def pg(ws, L=L, srcs=srcs, d=d):
+                K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=ws)
+                if L.b is not None:
+                    K.colsum(d, L.db(garena), ws, c_out=L.cout)
+            self._param_grads(side, pg)
             g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
             outs = [g_skip[k]]
             if k < D - 1:
@@ -363,9 +379,11 @@ class GeneratorEngine(_Engine):
                 dr = self._bn_backward(L, ctx, f"e{k}", raw, B * h * w, garena, g_down, K.ACT_LRELU, g_skip[k],
                                        K.ACT_RELU)
             src = v["x"] if k == 0 else v["aL"][k - 1]
-            K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=self.ws)
-            if L.b is not None:
-                K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
+            def pg(ws, L=L, dr=dr, src=src):
+                K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=ws)
+                if L.b is not None:
+                    K.colsum(dr, L.db(garena), ws, c_out=L.cout)
+            self._param_grads(side, pg)
             if k > 0:
                 g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                 K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
@@ -430,7 +448,7 @@ class DiscriminatorEngine(_Engine):
             a, h, w = [out], ho, wo
         return a[0]
 
-    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False):
+    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55)."""
         if not ctx.v.get("train", False):
@@ -454,9 +472,11 @@ class DiscriminatorEngine(_Engine):
                                        param_grads=param_grads)
             inputs = v["srcs"] if i == 0 else [v["a"][i - 1]]
             if param_grads:
-                K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=self.ws)
-                if L.b is not None:
-                    K.colsum(dr, L.db(garena), self.ws, c_out=L.cout)
+                def pg(ws, L=L, dr=dr, inputs=inputs):
+                    K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=ws)
+                    if L.b is not None:
+                        K.colsum(dr, L.db(garena), ws, c_out=L.cout)
+                self._param_grads(side, pg)
             if i > 0 or need_dx:
                 hin, win = inputs[0].shape[1:3]
                 cp = sum(L.in_pad)

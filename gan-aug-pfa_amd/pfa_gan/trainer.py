@@ -88,7 +88,7 @@ class GanTrainer:
     """Owns the engines, contexts and optimizers of one (generator, discriminator) pair on one GPU."""
 
     def __init__(self, gen, disc, opt_g=None, opt_d=None, precision="bf16", lambda_l1=LAMBDA_L1, process_group=None,
-                 use_graph=False):
+                 use_graph=False, overlap=True):
         self.gen, self.disc = gen, disc
         self.dtype = resolve_dtype(precision)
         nc_a = gen.input_nc
@@ -112,6 +112,8 @@ class GanTrainer:
         self.loss_sums = torch.zeros(2, dtype=torch.float32, device=dev)
         self.nsteps = 0
         self.use_graph = use_graph
+        # second HIP stream: parameter-gradient kernels run under the dgrad/BatchNorm chain, D(real) under G forward
+        self.side = torch.cuda.Stream(device=dev) if overlap else None
         self._graphs = None
         self._static = None
         self.G.refresh_shadows(force=True)
@@ -122,16 +124,28 @@ class GanTrainer:
         G, Dn = self.G, self.Dn
         K.fill_zero(self.losses)
         self.opt_d.zero_grad()
+        main = torch.cuda.current_stream()
+        if self.side is not None:            # D(real) does not need the generator: run it beside the G forward
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                lr = Dn.forward([xa, xb], self.ctx_r, train=True)
+                dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
+                K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
-        lr = Dn.forward([xa, xb], self.ctx_r, train=True)
-        dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-        K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+        if self.side is not None:
+            main.wait_stream(self.side)
+        else:
+            lr = Dn.forward([xa, xb], self.ctx_r, train=True)
+            dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
+            K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
         lf = Dn.forward([xa, fake], self.ctx_f, train=True)
         dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
         K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
         garena = self.opt_d.flat().grad
-        Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
-        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
+        Dn.backward(self.ctx_r, dl_r, garena, param_grads=True, side=self.side)
+        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side)
+        if self.side is not None:
+            main.wait_stream(self.side)
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
@@ -145,7 +159,9 @@ class GanTrainer:
         dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True)
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
         K.l1_tanh_bwd(fake, xb, G.out_nc, dx, xa.shape[3], self.lambda_l1, self.losses[1:2], dpre)
-        G.backward(self.gctx, dpre, self.opt_g.flat().grad)
+        G.backward(self.gctx, dpre, self.opt_g.flat().grad, side=self.side)
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _g_update(self, graph_safe):
         self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
