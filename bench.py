@@ -77,12 +77,12 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     import pfa_gan.engine as E
     E.K.gather_gemm = timed
     try:
-        was_graph = trainer.use_graph
-        trainer.use_graph = False
+        was_graph, was_side = trainer.use_graph, trainer.side
+        trainer.use_graph, trainer.side = False, None      # one stream: nothing else shares the GPU with the timed launches
         for _ in range(steps):
             trainer.step_packed(xa, xb)
         torch.cuda.synchronize()
-        trainer.use_graph = was_graph
+        trainer.use_graph, trainer.side = was_graph, was_side
     finally:
         K.gather_gemm = real
         E.K.gather_gemm = real

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_bn_act(const T* __restrict__ raw, int64
 
 // ------------------------------------------------------------------ BatchNorm backward, pass 1
 // dy = act1'(y) g1 + act2'(y) g2 ; partial sums of dy and dy*xhat per channel and block.
-constexpr int BWD_PASSES = 16;
+constexpr int BWD_PASSES = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw, int64_t rows, int c, int cpr,
                                                        const float* __restrict__ scale,
@@ -550,7 +550,7 @@ extern "C" int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const
 // rows per block: fewer passes for small tensors so that even a 4x4 map spreads over the chip
 static int bwd_passes(int64_t rows, int cpr) {
     const int rpp = 256 / cpr;
-    int64_t p = rows / ((int64_t)rpp * 1024);
+    int64_t p = (rows + (int64_t)rpp * 512 - 1) / ((int64_t)rpp * 512);     // <= ~512 partial tiles for the finalize
     return p < 1 ? 1 : (p > BWD_PASSES ? BWD_PASSES : (int)p);
 }
 

@@ -73,8 +73,12 @@ def choose_splitk(mode, M, n, ctot, dtype):
     classes = 4 if mode == TCONV_S2 else 1
     blocks = math.ceil(M / bm) * math.ceil(n / bn) * classes
     ksteps = math.ceil((4 if mode == TCONV_S2 else 16) * (ctot // ch_of(dtype)) / 8)
-    if blocks >= 192 or ksteps < 8:
+    if ksteps < 8:
         return 1
+    if blocks >= 192:
+        # exactly one workgroup per CU and a long K loop: two slices give every CU a second, independent workgroup
+        # to overlap with (measured: c4 dgrad 104 -> 84 us, d4 61 -> 54 us; no gain once K is short)
+        return 2 if blocks < 384 and ksteps >= 64 and n % 4 == 0 else 1
     return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
 
 
