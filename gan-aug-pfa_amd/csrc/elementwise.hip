@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 __global__ void k_adam_tick(int32_t* step) { *step += 1; }
 
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
-                                              float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                              float b1, float b2, float eps, int step, const int32_t* step_dev,
-                                              float grad_scale) {
+                                              const float* __restrict__ g2, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float lr, float b1, float b2,
+                                              float eps, int step, const int32_t* step_dev, float grad_scale) {
     const int t = step_dev ? *step_dev : step;
     // torch: step_size = lr/(1-b1^t); denom = sqrt(v)/sqrt(1-b2^t) + eps
     const float bc1 = 1.f - powf(b1, (float)t);
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        if (g2) gg += ((const f32x4*)g2)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ge = gg[e] * grad_scale;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        const float ge = g[i] * grad_scale;
+        const float ge = (g[i] + (g2 ? g2[i] : 0.f)) * grad_scale;
         const float me = b1 * m[i] + (1.f - b1) * ge;
         const float ve = b2 * v[i] + (1.f - b2) * ge * ge;
         m[i] = me; v[i] = ve;
@@ -666,12 +667,13 @@ extern "C" int pfa_colsum(const void* x, int64_t rows, int c, int c_out, int dty
     return 0;
 }
 
-extern "C" int pfa_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                        float eps, int step, const int32_t* step_dev, float grad_scale, pfa_stream s) {
+extern "C" int pfa_adam(float* p, const float* g, const float* g2, float* m, float* v, int64_t n, float lr, float beta1,
+                        float beta2, float eps, int step, const int32_t* step_dev, float grad_scale, pfa_stream s) {
     PFA_REQUIRE(p && g && m && v && n > 0, "pfa_adam: bad arguments");
     PFA_REQUIRE(step_dev || step >= 1, "pfa_adam: step must be >= 1");
     PFA_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "pfa_adam: arenas must be 16-byte aligned");
-    hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr,
+    PFA_REQUIRE(!g2 || (uintptr_t)g2 % 16 == 0, "pfa_adam: second gradient arena must be 16-byte aligned");
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, g2, m, v, n, lr,
                        beta1, beta2, eps, step, step_dev, grad_scale);
     PFA_LAUNCHED("k_adam");
     return 0;

@@ -248,38 +248,52 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
     const int lrow = lane & 15, kk = lane >> 4;
     // A K-step in three phases: (1) all 2*(FN+FM) fragment reads, (2) issue of the next tile's DMA (its address
     // arithmetic runs under the LDS latency), (3) the MFMAs, which the DMA then overlaps.
-    typename Mma<T>::frag wf[2][FN], af[2][FM];
-    auto read_frags = [&](int buf) {
-        if (p.dbg & 4) return;
+    // Small per-wave tiles read both 64-byte halves of the K-step at once (one LDS latency per K-step); the 64x128
+    // per-wave tile of the 256x256 block would not fit its fragments twice and reads half by half.
+    constexpr bool ALL_AT_ONCE = (FN + FM) <= 8;
+    constexpr int NH = ALL_AT_ONCE ? 2 : 1;
+    typename Mma<T>::frag wf[NH][FN], af[NH][FM];
+    auto read_half = [&](int buf, int h, int slot) {
         const char* abase = smem + buf * STAGE;
         const char* wbase = abase + A_BYTES;
+        const int ch = kk + 4 * h;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ch = kk + 4 * h;
-#pragma unroll
-            for (int a = 0; a < FN; ++a) {
-                const int row = wn * TN + a * 16 + lrow;
-                wf[h][a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int b = 0; b < FM; ++b) {
-                const int row = wm * TM + b * 16 + lrow;
-                af[h][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
-            }
+        for (int a = 0; a < FN; ++a) {
+            const int row = wn * TN + a * 16 + lrow;
+            wf[slot][a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
         }
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int row = wm * TM + b * 16 + lrow;
+            af[slot][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto mfma_half = [&](int slot) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[slot][a], af[slot][b], acc[a][b]);
+    };
+    // phase 1: fragment reads; phase 2 (caller): issue of the next tile's DMA; phase 3: MFMAs under that DMA
+    auto read_frags = [&](int buf) {
+        if (p.dbg & 4) return;
+        read_half(buf, 0, 0);
+        if constexpr (ALL_AT_ONCE) read_half(buf, 1, 1);
         __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead (the scheduler sinks them otherwise)
     };
-    auto mfma_frags = [&]() {
+    auto mfma_frags = [&](int buf) {
         if (p.dbg & 4) return;
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[h][a], af[h][b], acc[a][b]);
+        mfma_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ALL_AT_ONCE) {
+            mfma_half(1);
+        } else {
+            read_half(buf, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
+            mfma_half(0);
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     const int ks0 = split * p.kper;
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             __syncthreads();          // waits vmcnt(0): stage ks has landed; everyone is done reading buf^1
             read_frags(buf);
             if (ks + 1 < ks1) stage(ks + 1, buf ^ 1);
-            mfma_frags();
+            mfma_frags(buf);
         }
     } else {
         const int nks = ks1 - ks0;
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             __builtin_amdgcn_s_barrier();   // every wave's step-i data is in LDS; everyone finished reading ring slot (i-1)%3
             read_frags(buf);
             if (i + 2 < nks) stage(ks0 + i + 2, buf == 0 ? 2 : buf - 1);
-            mfma_frags();
+            mfma_frags(buf);
             buf = buf == 2 ? 0 : buf + 1;
         }
     }
@@ -589,13 +603,18 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 // ---- tile configuration
 // id 0: 128x128, 4 waves, 2 stages   id 1: 128x64, 4 waves, 2 stages   id 2: 256x16, 4 waves, 2 stages
 // id 3: 128x128, 4 waves, 3-stage ring   id 4: 256x128, 8 waves, 3-stage ring
+// id 5: 256x128, 8 waves, 2 stages        id 6: 256x256, 8 waves, 2 stages (128 KiB LDS, one workgroup per CU)
 struct TileCfg { int id, bm, bn; };
 
 inline TileCfg choose_cfg(const GatherK& k) {
-    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 128, 128}, {4, 256, 128}};
+    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 128, 128}, {4, 256, 128},
+                                   {5, 256, 128}, {6, 256, 256}};
     if (k.n <= 16) return cfgs[2];
     if (k.n <= 64) return cfgs[1];
-    if (g_knob[0] >= 1 && g_knob[0] <= 5 && cfgs[g_knob[0] - 1].bn == 128) return cfgs[g_knob[0] - 1];
+    if (g_knob[0] >= 1 && g_knob[0] <= 7 && cfgs[g_knob[0] - 1].bn >= 128) {
+        const TileCfg c = cfgs[g_knob[0] - 1];
+        if (c.bn == 128 || k.n >= 256) return c;        // the 256-wide tile only where it is filled
+    }
     return cfgs[0];
 }
 
@@ -637,7 +656,9 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 1: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
         case 2: return launch_gather<T, 256, 16, 4, 1, 2>(k, classes, st);
         case 3: return launch_gather<T, 128, 128, 2, 2, 3>(k, classes, st);
-        default: return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+        case 4: return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+        case 5: return launch_gather<T, 256, 128, 4, 2, 2>(k, classes, st);
+        default: return launch_gather<T, 256, 256, 4, 2, 2>(k, classes, st);
     }
 }
 

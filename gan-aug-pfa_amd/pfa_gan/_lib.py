@@ -71,7 +71,7 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p]),
     "pfa_colsum_ws": (c_size_t, [c_int64, c_int]),
     "pfa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "pfa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
+    "pfa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,
                          c_void_p, c_float, c_void_p]),
     "pfa_adam_tick": (c_int, [c_void_p, c_void_p]),
     "pfa_weight_shadow": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

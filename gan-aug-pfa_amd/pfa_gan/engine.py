@@ -168,8 +168,10 @@ class _Engine:
         self.module, self.dtype = module, dtype
         self.flat = flat_of(module)
         self.device = self.flat.device
-        self.ws = K.Workspace(self.device)
-        self.ws_side = K.Workspace(self.device)
+        self.ws = K.Workspace(self.device)           # main-stream scratch
+        self.ws_side = K.Workspace(self.device)      # scratch of the parameter-gradient stream
+        self.ws_alt = K.Workspace(self.device)       # scratch of a whole pass that runs on another stream
+        self.ws_cur = self.ws
         self.layers = []
         self._versions = None
         self._scratch = None
@@ -184,7 +186,7 @@ class _Engine:
         stream (fork here; the caller joins before the optimizer).  Their workspace is not shared with the main
         stream's kernels."""
         if side is None:
-            fn(self.ws)
+            fn(self.ws_cur)
             return
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -251,7 +253,7 @@ class _Engine:
         dy = ctx.buf(tag + ".dy", raw.shape, raw.dtype)
         scale, shift = ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32)
         mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
-        part, nt = K.bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, self.ws)
+        part, nt = K.bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, self.ws_cur)
         coef = ctx.buf(tag + ".coef", (3 * c,), f32)
         dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
         dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
@@ -262,7 +264,7 @@ class _Engine:
     def _act_backward(self, ctx, tag, act_out, g1, act1, g2=None, act2=K.ACT_NONE):
         """Conv output without a norm: its gradient is act'(.)*g, and sign(act_out) == sign(pre-activation)."""
         dr = ctx.buf(tag + ".dy", act_out.shape, act_out.dtype)
-        K.bn_bwd_reduce(act_out, None, None, None, None, g1, act1, g2, act2, dr, self.ws)
+        K.bn_bwd_reduce(act_out, None, None, None, None, g1, act1, g2, act2, dr, self.ws_cur)
         return dr
 
 
@@ -448,11 +450,19 @@ class DiscriminatorEngine(_Engine):
             a, h, w = [out], ho, wo
         return a[0]
 
-    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None):
+    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55)."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
+        # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
+        self.ws_cur = self.ws_alt if alt_ws else self.ws
+        try:
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side)
+        finally:
+            self.ws_cur = self.ws
+
+    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -482,9 +492,9 @@ class DiscriminatorEngine(_Engine):
                 cp = sum(L.in_pad)
                 g = ctx.buf(f"g.c{i}", (B, hin, win, cp), dt)
                 if L.stride == 2:
-                    K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, cp, [g], (B, ho, wo), self.ws)
+                    K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, cp, [g], (B, ho, wo), self.ws_cur)
                 else:
-                    K.gather_gemm(K.CONV_S1_DGRAD, [dr], L.w_bwd, cp, [g], (B, hin, win), self.ws)
+                    K.gather_gemm(K.CONV_S1_DGRAD, [dr], L.w_bwd, cp, [g], (B, hin, win), self.ws_cur)
                 if i == 0:
                     dx = g
         return dx

@@ -230,9 +230,9 @@ def colsum(x, out, ws, c_out=None):
 
 
 # ------------------------------------------------------------------------------- Adam, shadows, layout
-def adam(p, g, m, v, lr, b1, b2, eps, step, step_dev=None, grad_scale=1.0):
-    check(lib().pfa_adam(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, int(step), ptr(step_dev),
-                         float(grad_scale), stream()), "pfa_adam")
+def adam(p, g, m, v, lr, b1, b2, eps, step, step_dev=None, grad_scale=1.0, g2=None):
+    check(lib().pfa_adam(ptr(p), ptr(g), ptr(g2), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, int(step),
+                         ptr(step_dev), float(grad_scale), stream()), "pfa_adam")
 
 
 def adam_tick(step_dev):

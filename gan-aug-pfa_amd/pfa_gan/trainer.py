@@ -54,21 +54,30 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat = flat
         return self._flat
 
+    def grad2(self):
+        """Second gradient arena (same layout) for a backward pass that runs concurrently on another stream."""
+        if getattr(self, "_grad2", None) is None or self._grad2.numel() != self.flat().total:
+            self._grad2 = torch.zeros_like(self.flat().grad)
+        return self._grad2
+
     def zero_grad(self, set_to_none=False):
         K.fill_zero(self.flat().grad)
+        if getattr(self, "_grad2", None) is not None:
+            K.fill_zero(self._grad2)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, graph_safe=False):
+    def step(self, closure=None, grad_scale=1.0, graph_safe=False, use_grad2=False):
         flat = self.flat()
         g = self.param_groups[0]
+        g2 = self._grad2 if use_grad2 else None
         self.steps += 1
         if graph_safe:      # step count read from device memory so that a captured launch stays valid on replay
             K.adam_tick(self.step_dev)
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0,
-                   step_dev=self.step_dev, grad_scale=grad_scale)
+                   step_dev=self.step_dev, grad_scale=grad_scale, g2=g2)
         else:
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.steps,
-                   grad_scale=grad_scale)
+                   grad_scale=grad_scale, g2=g2)
 
     def state_dict(self):
         self.flat()
@@ -114,6 +123,8 @@ class GanTrainer:
         self.use_graph = use_graph
         # second HIP stream: parameter-gradient kernels run under the dgrad/BatchNorm chain, D(real) under G forward
         self.side = torch.cuda.Stream(device=dev) if overlap else None
+        self.side2 = torch.cuda.Stream(device=dev) if overlap else None
+        self._ev_real_fwd = torch.cuda.Event() if overlap else None
         self._graphs = None
         self._static = None
         self.G.refresh_shadows(force=True)
@@ -123,33 +134,45 @@ class GanTrainer:
     def _d_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
         K.fill_zero(self.losses)
-        self.opt_d.zero_grad()
-        main = torch.cuda.current_stream()
-        if self.side is not None:            # D(real) does not need the generator: run it beside the G forward
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                lr = Dn.forward([xa, xb], self.ctx_r, train=True)
-                dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-                K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
-        fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
-        if self.side is not None:
-            main.wait_stream(self.side)
-        else:
+        garena = self.opt_d.flat().grad
+        if self.side is None:
+            self.opt_d.zero_grad()
+            fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
             K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+            lf = Dn.forward([xa, fake], self.ctx_f, train=True)
+            dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
+            K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
+            Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
+            Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
+            return
+        # Three streams.  side: the whole D(real) forward + backward (it needs neither the generator nor D(fake)) into
+        # the second gradient arena; main: G forward -> D(fake) forward -> D(fake) dgrad/BatchNorm chain; side2: D(fake)'s
+        # parameter gradients.  D(real)'s forward finishes before D(fake)'s starts, so the BatchNorm running buffers are
+        # updated in the reference's order (real, then fake: train_gan.py:57,59).
+        main = torch.cuda.current_stream()
+        garena2 = self.opt_d.grad2()
+        self.opt_d.zero_grad()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            lr = Dn.forward([xa, xb], self.ctx_r, train=True)
+            dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
+            K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+            self._ev_real_fwd.record(self.side)
+            Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True)
+        fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
+        main.wait_event(self._ev_real_fwd)
         lf = Dn.forward([xa, fake], self.ctx_f, train=True)
         dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
         K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
-        garena = self.opt_d.flat().grad
-        Dn.backward(self.ctx_r, dl_r, garena, param_grads=True, side=self.side)
-        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side)
-        if self.side is not None:
-            main.wait_stream(self.side)
+        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side2)
+        main.wait_stream(self.side)
+        main.wait_stream(self.side2)
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
-        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
+        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=self.side is not None)
         Dn.refresh_shadows(force=True)
         self.opt_g.zero_grad()
         fake = self.gctx.v["fake"]
@@ -170,6 +193,9 @@ class GanTrainer:
 
     def _allreduce(self, opt):
         if self.world > 1:
+            if opt is self.opt_d and self.side is not None:      # fold the second arena in before the collective
+                opt.flat().grad.add_(opt.grad2())
+                opt.grad2().zero_()
             torch.distributed.all_reduce(opt.flat().grad, group=self.pg)
 
     # ----------------------------------------------------------------------------------- public API

@@ -170,9 +170,10 @@ int pfa_colsum(const void* x, int64_t rows, int c, int c_out, int dtype, float* 
 /* ------------------------------------------------------------------ Adam (train_gan.py:140-141) */
 /* torch.optim.Adam, weight_decay 0, amsgrad off, over one flat float32 arena.  `step` is the 1-based
  * step count of THIS update; when step_dev != NULL the count is read from device memory instead
- * (hipGraph replay) after being incremented by pfa_adam_tick. */
-int pfa_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-             int step, const int32_t* step_dev, float grad_scale, pfa_stream s);
+ * (hipGraph replay) after being incremented by pfa_adam_tick.  The gradient is grad_scale * (g + g2); g2 (optional) lets
+ * two backward passes that ran concurrently on different streams keep separate, race-free gradient arenas. */
+int pfa_adam(float* p, const float* g, const float* g2, float* m, float* v, int64_t n, float lr, float beta1,
+             float beta2, float eps, int step, const int32_t* step_dev, float grad_scale, pfa_stream s);
 int pfa_adam_tick(int32_t* step_dev, pfa_stream s);
 
 /* ------------------------------------------------------------------ layout / precision plumbing */
