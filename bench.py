@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer = BASELINE config 5: generator-only eval forward (generate_synthetic_data.py:55-68), tiles/s")
     return ap.parse_args()
 
 
@@ -54,12 +56,15 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     from pfa_gan import kernels as K
     real = K.gather_gemm
     rec = []
+    alg_bytes = []
 
     def timed(mode, srcs, w, n, outs, grid, ws, **kw):
         splitk = kw.get("splitk")
         ctot = sum(s.shape[3] for s in srcs)
         if splitk is None:
             splitk = K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, ctot, srcs[0].dtype)
+        if n > 64:      # every launch of this instantiation: unique operand + result bytes (what the PMC pass also covers)
+            alg_bytes.append(sum(t.numel() * t.element_size() for t in list(srcs) + list(outs)) + w.numel() * w.element_size())
         dominant = n > 64 and splitk == 1          # -> k_gather_gemm<T,128,128,2,2>, no split-K slab
         if not dominant:
             return real(mode, srcs, w, n, outs, grid, ws, **kw)
@@ -90,8 +95,17 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     flops = sum(f for _, _, f in rec)
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     achieved = flops / (ms * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic_gather128.json")
+    if precision == "bf16" and xa.shape[0] == 16 and xa.shape[1] == 256 and os.path.exists(tfile):
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.py);
+        # counters cannot be read from inside the process being measured
+        t = json.load(open(tfile))
+        traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather128.json"
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                traffic=None, kernel=f"k_gather_gemm<{precision},128,128,2,2>", launches_per_step=len(rec) // steps,
+                traffic=traffic, traffic_source=traffic_src,
+                algorithmic_bytes_per_launch=round(sum(alg_bytes) / max(len(alg_bytes), 1)),
+                kernel=f"k_gather_gemm<{precision},128,128,2,2>", launches_per_step=len(rec) // steps,
                 avg_launch_us=round(1e3 * ms / len(rec), 2), flop_per_launch=round(flops / len(rec)),
                 flop_share_of_step=round(flops / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3))
 
@@ -117,8 +131,48 @@ def cpu_baseline(size, steps):
                        f"{size}x{size}, batch {b}, {steps} steps after 1 warm-up, fp32")
 
 
+def infer_main(args):
+    """BASELINE config 5: eval-mode generator forward over synthetic 256x256 tiles, hipGraph-captured, one GPU."""
+    import pfa_gan
+    from pfa_gan import kernels as K
+    torch.manual_seed(0)
+    gen = pfa_gan.UNetGenerator(3, 3).cuda().set_precision(args.precision).eval()
+    eng = gen.engine()
+    eng.refresh_shadows(force=True)
+    ctx = eng.new_ctx()
+    x = torch.rand((args.batch, 3, args.size, args.size), device="cuda") * 2 - 1
+    xh = K.pack_nhwc(x, eng.dtype)
+    out_u8 = None
+    for _ in range(3):
+        eng.forward(xh, ctx, train=False)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fake = eng.forward(xh, ctx, train=False)
+    for _ in range(args.warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tiles = args.batch * args.steps / dt
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    print(json.dumps({
+        "metric": "generator-only eval forward, 256x256 tiles/s", "value": round(tiles, 1), "unit": "tiles/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"UNetGenerator eval forward, {args.size}x{args.size}, batch {args.batch}, hipGraph replay"},
+        "step_mfma": {"algorithmic_tflops_per_gpu": round(tiles * 12.046e9 / 1e12, 2),
+                      "frac_of_peak": round(tiles * 12.046e9 / 1e12 / peak, 4)}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.mode == "infer":
+        torch.cuda.set_device(0)
+        return infer_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
