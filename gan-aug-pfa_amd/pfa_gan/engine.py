@@ -338,9 +338,20 @@ class GeneratorEngine(_Engine):
         ctx.v["fake"] = fake
         return fake
 
-    def backward(self, ctx, dpre, garena, side=None):
+    def grad_buckets(self):
+        """Contiguous ranges of the gradient arena in the order the backward completes them:
+        [decoder d7..d1] (final when the decoder loop ends), [e_{D-2}..e_D] (final after the three innermost
+        encoder levels), [e1..e_{D-3}] (end of backward).  Arena order is module.parameters() order:
+        e1, e2, bn2, ..., eD, dD, bnD, ..., d2, bn2, d1 - so each bucket is one slice."""
+        off = lambda L: self.flat.slots[id(L.w)][0]
+        x_dec = off(self.up[self.D - 1])
+        x_mid = off(self.down[max(self.D - 3, 1)])
+        return [(x_dec, self.flat.total), (x_mid, x_dec), (0, x_mid)], max(self.D - 3, 1)
+
+    def backward(self, ctx, dpre, garena, side=None, bucket_ready=None):
         """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena.
-        side: optional second stream for the parameter-gradient kernels (join it before using garena)."""
+        side: optional second stream for the parameter-gradient kernels (join it before using garena).
+        bucket_ready(i): called when grad_buckets()[0][i] has had all its kernels issued (data parallel overlap)."""
         if not ctx.v.get("train", False):
             raise PfaError("generator backward needs a training-mode forward")
         D, dt = self.D, self.dtype
@@ -367,6 +378,9 @@ class GeneratorEngine(_Engine):
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
                 outs.append(g_up[k + 1])
             K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, outs, (B, h, w), self.ws)
+        mid_level = self.grad_buckets()[1]
+        if bucket_ready is not None:
+            bucket_ready(0)
         # ---- encoder, innermost first
         g_down = None
         for k in range(D - 1, -1, -1):
@@ -386,9 +400,13 @@ class GeneratorEngine(_Engine):
                 if L.b is not None:
                     K.colsum(dr, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
+            if bucket_ready is not None and k == mid_level and k > 0:
+                bucket_ready(1)
             if k > 0:
                 g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                 K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
+        if bucket_ready is not None:
+            bucket_ready(2 if mid_level > 0 else 1)
 
 
 # ------------------------------------------------------------------------------------ discriminator

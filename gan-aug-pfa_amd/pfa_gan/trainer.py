@@ -115,6 +115,7 @@ class GanTrainer:
         self.lambda_l1 = float(lambda_l1)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self._g_reduced = False
         dev = self.G.device
         self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)     # [loss_d, loss_g] of the last step
@@ -182,9 +183,29 @@ class GanTrainer:
         dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True)
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
         K.l1_tanh_bwd(fake, xb, G.out_nc, dx, xa.shape[3], self.lambda_l1, self.losses[1:2], dpre)
-        G.backward(self.gctx, dpre, self.opt_g.flat().grad, side=self.side)
+        garena = self.opt_g.flat().grad
+        self._works = []
+        hook = None
+        if self.pg is not None and self.side is not None and not graph_safe:
+            buckets = G.grad_buckets()[0]
+            main = torch.cuda.current_stream()
+
+            def hook(i):
+                # bucket i is complete once the side stream (weight gradients) and the main stream (BatchNorm
+                # gamma/beta gradients) reach this point; the RCCL collective is enqueued behind the side stream
+                # and runs on the communicator's own stream while both streams go on with the remaining backward
+                lo, hi = buckets[i]
+                if hi <= lo:
+                    return
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._works.append(torch.distributed.all_reduce(garena[lo:hi], group=self.pg, async_op=True))
+        G.backward(self.gctx, dpre, garena, side=self.side, bucket_ready=hook)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        for w in self._works:
+            w.wait()                 # the current stream waits for the collective; no host sync
+        self._g_reduced = hook is not None
 
     def _g_update(self, graph_safe):
         self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
@@ -192,7 +213,10 @@ class GanTrainer:
         self.loss_sums += self.losses
 
     def _allreduce(self, opt):
-        if self.world > 1:
+        if self.pg is not None:
+            if opt is self.opt_g and getattr(self, "_g_reduced", False):
+                self._g_reduced = False          # already reduced bucket by bucket during the backward
+                return
             if opt is self.opt_d and self.side is not None:      # fold the second arena in before the collective
                 opt.flat().grad.add_(opt.grad2())
                 opt.grad2().zero_()

@@ -254,3 +254,40 @@ def test_gpu_input_without_library_path_is_an_error(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpfa_hip.so")
     with pytest.raises(_lib.PfaError, match="mandatory"):
         pfa_gan.kernels.pack_nhwc(torch.zeros(1, 3, 4, 4, device="cuda"), torch.float32)
+
+
+def test_data_parallel_code_path_single_rank_rccl(golden):
+    """The data-parallel trainer path (rank-0 broadcast, D-gradient all-reduce with the second arena folded in, bucketed
+    asynchronous all-reduce of the generator arena issued from the side stream during the backward) on a 1-rank RCCL
+    group: every collective call is the real one, and the result must equal the single-process step exactly in
+    schedule (same goldens).  Multi-rank semantics are covered on gloo in tests/test_host_cpu.py."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 1000)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        name, nd, ngf, ndf, n, h, steps = STEP_CASES[0]
+        z = golden("step")
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+        load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+        load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+        tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=dist.group.WORLD)
+        pfa_gan.broadcast_model(G, dist.group.WORLD)
+        pfa_gan.broadcast_model(D, dist.group.WORLD)
+        tr.G.refresh_shadows(force=True)
+        tr.Dn.refresh_shadows(force=True)
+        buckets, _ = tr.G.grad_buckets()
+        assert sorted(buckets)[0][0] == 0 and sorted(buckets)[-1][1] == tr.G.flat.total
+        assert all(a[1] == b[0] for a, b in zip(sorted(buckets), sorted(buckets)[1:])), "buckets must tile the arena"
+        seed = int(z[f"step.{name}.seed"])
+        for i in range(steps):
+            a = torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).cuda()
+            b = torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).cuda()
+            losses = tr.step(a, b).cpu().numpy()
+            assert_close(losses[0], z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
+            assert_close(losses[1], z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
+        _check_step_state(z, name, G, D)
+    finally:
+        dist.destroy_process_group()
