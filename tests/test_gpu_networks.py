@@ -291,3 +291,41 @@ def test_data_parallel_code_path_single_rank_rccl(golden):
         _check_step_state(z, name, G, D)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision,n,h", [("fp32", 1, 128), ("bf16", 1, 256), ("bf16", 3, 128), ("fp32", 2, 256)],
+                         ids=lambda v: str(v))
+def test_full_size_step_vs_oracle(precision, n, h):
+    """Default networks (41.8 M + 2.77 M parameters), one fused step against oracle/step.py on the same weights and data:
+    the reference's own batch size 1 (train_gan.py:26), a ragged batch of 3, and 256x256."""
+    gst = fill.fill_state(nets.g_state_shapes(), seed=21, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(), seed=22, bn_noise=False)
+    a = fill.uniform(f"fs.a.{n}.{h}", (n, 3, h, h))
+    b = fill.uniform(f"fs.b.{n}.{h}", (n, 3, h, h))
+    G = pfa_gan.UNetGenerator(3, 3).cuda()
+    D = pfa_gan.NLayerDiscriminator(6).cuda()
+    load(G, gst)
+    load(D, dst)
+    tr = pfa_gan.GanTrainer(G, D, precision=precision)
+    losses = tr.step(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    og, od = {k: v.copy() for k, v in gst.items()}, {k: v.copy() for k, v in dst.items()}
+    ld, lg, ex = ostep.gan_step(og, od, ostep.new_adam_state(og), ostep.new_adam_state(od), a, b)
+    rel = 2e-4 if precision == "fp32" else 2e-2
+    assert_close(losses[0], ld, 0, rel, f"loss_d {precision}")
+    assert_close(losses[1], lg, 0, rel, f"loss_g {precision}")
+    fake = pfa_gan.kernels.unpack_nchw(tr.gctx.v["fake"], 3).cpu().numpy()
+    if precision == "fp32":
+        assert_close(fake, ex["fake_b"], ABS, REL, "fake_B")
+        for k in ("model.model.1.model.2.running_mean", "model.model.1.model.3.model.3.model.6.running_var"):
+            assert_close(G.state_dict()[k].cpu().numpy(), og[k], 1e-5, 1e-3, k)
+        # Adam's first step moves every parameter by ~lr in the direction of -sign(g): compare the moved weights
+        for k in ("model.model.0.weight", "model.model.3.weight", "model.model.1.model.3.model.3.model.1.weight"):
+            got = fill.compact(G.state_dict()[k].cpu().numpy())
+            want = fill.compact(og[k])
+            assert np.mean(np.abs(got - want) > 2e-5) < 0.02, k
+    else:
+        assert np.abs(fake - ex["fake_b"]).mean() < 2e-2
+    assert int(G.state_dict()["model.model.1.model.2.num_batches_tracked"]) == 2
+    assert int(D.state_dict()["model.3.num_batches_tracked"]) == 3
+    for t in list(G.state_dict().values()) + list(D.state_dict().values()):
+        assert torch.isfinite(t.float()).all()
