@@ -177,9 +177,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
     // ---- wide staging (channel counts that are multiples of one K-step: every MFMA-heavy layer).
     //      A K-step lies inside one (tap, source) segment, so the row pointers are rebuilt only when the
     //      segment changes and otherwise just advance by 128 bytes: ~2 VALU ops per row per K-step.
-    const char* a_ptr[AROWS];
-    const char* w_ptr[WROWS];
-    int a_inc[AROWS], w_inc[WROWS];
+    // Per row: a 32-bit byte offset from the segment's base pointer (tensors are < 4 GiB) and one validity bit; invalid
+    // rows (padding taps, rows >= M, weight rows >= N) read the zero page and do not advance.
+    unsigned a_off[AROWS], w_off[WROWS];
+    unsigned okmask = 0;                 // bit i: activation row i valid; bit 16+i: weight row i valid
+    const char* seg_base = p.src1;
     int seg_tap = 0, seg_part = 0, seg_left = 0;
     auto seg_setup = [&](int kc) {      // kc: K-step offset inside the segment (non-zero only for a split-K start)
         int ty, tx, widx;
@@ -190,25 +192,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             ty = seg_tap >> 2; tx = seg_tap & 3;
             widx = seg_tap;
         }
-        const char* sbase = seg_part ? p.src2 : p.src1;
+        seg_base = seg_part ? p.src2 : p.src1;
         const int csrc = seg_part ? p.c2 : p.c1;
         const int cc = (kc * 8 + g) * CH;
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
             const int y = (a_yx[i] >> 16) + sgn * ty;
             const int x = (int)(short)(a_yx[i] & 0xffff) + sgn * tx;
             const bool ok = (a_img[i] >= 0) & ((unsigned)y < (unsigned)p.hs) & ((unsigned)x < (unsigned)p.ws);
-            const long long off = ((long long)(a_img[i] + y * p.ws + x) * csrc + cc) * (long long)sizeof(T);
-            a_ptr[i] = ok ? sbase + off : zero;
-            a_inc[i] = ok ? 128 : 0;
+            a_off[i] = (unsigned)(((a_img[i] + y * p.ws + x) * csrc + cc) * (int)sizeof(T));
+            okmask |= ok ? (1u << i) : 0u;
         }
         const int cw = (seg_part ? p.c1 : 0) + cc;
 #pragma unroll
         for (int i = 0; i < WROWS; ++i) {
             const int n = n0 + r0 + RSTEP * i;
-            const bool ok = n < p.n;
-            w_ptr[i] = ok ? p.w + ((long long)(n * 16 + widx) * p.ctot + cw) * (long long)sizeof(T) : zero;
-            w_inc[i] = ok ? 128 : 0;
+            w_off[i] = (unsigned)((((n * 16 + widx) * p.ctot) + cw) * (int)sizeof(T));
+            okmask |= (n < p.n) ? (1u << (16 + i)) : 0u;
         }
         seg_left = (seg_part ? p.spt - p.sp1 : p.sp1) - kc;
     };
@@ -217,14 +218,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         char* wbase = abase + A_BYTES;
 #pragma unroll
         for (int i = 0; i < AROWS; ++i) {
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(a_ptr[i]), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
-            a_ptr[i] += a_inc[i];
+            const bool ok = (okmask >> i) & 1u;
+            const char* gp = ok ? seg_base + a_off[i] : zero;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
+            a_off[i] += 128u;
         }
         if (wave < WWAVES) {
 #pragma unroll
             for (int i = 0; i < WROWS; ++i) {
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(w_ptr[i]), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
-                w_ptr[i] += w_inc[i];
+                const bool ok = (okmask >> (16 + i)) & 1u;
+                const char* gp = ok ? p.w + w_off[i] : zero;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+                w_off[i] += 128u;
             }
         }
         if (--seg_left == 0) {          // next segment: the other source of this tap, or the next tap
@@ -585,7 +590,10 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.splitk = (k.ksteps + k.kper - 1) / k.kper;     // no empty slices
     k.act = a->act; k.slope = a->slope;
     const int kstep_ch = 8 * ch;                  // channels per K-step
-    k.wide = (a->c1 % kstep_ch == 0 && a->c2 % kstep_ch == 0) ? 1 : 0;
+    const long long es = a->dtype == PFA_BF16 ? 2 : 4;
+    const bool small32 = (long long)a->nb * a->hs * a->ws * (a->c1 > a->c2 ? a->c1 : a->c2) * es < (1ll << 31) &&
+                         (long long)a->n * 16 * (a->c1 + a->c2) * es < (1ll << 31);
+    k.wide = (a->c1 % kstep_ch == 0 && a->c2 % kstep_ch == 0 && small32) ? 1 : 0;
     k.spt = k.wide ? k.ctot / kstep_ch : 1;
     k.sp1 = k.wide ? a->c1 / kstep_ch : 1;
     k.dbg = g_knob[1];
@@ -607,6 +615,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 struct TileCfg { int id, bm, bn; };
 
 inline TileCfg choose_cfg(const GatherK& k) {
+    const int classes = k.mode == PFA_TCONV_S2 ? 4 : 1;
     static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 128, 128}, {4, 256, 128},
                                    {5, 256, 128}, {6, 256, 256}};
     if (k.n <= 16) return cfgs[2];
@@ -615,6 +624,10 @@ inline TileCfg choose_cfg(const GatherK& k) {
         const TileCfg c = cfgs[g_knob[0] - 1];
         if (c.bn == 128 || k.n >= 256) return c;        // the 256-wide tile only where it is filled
     }
+    // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
+    // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
+    // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
+    (void)classes;
     return cfgs[0];
 }
 
