@@ -44,6 +44,12 @@ struct GatherK {
     int mtiles, ntiles, nwg;
     int wide, spt, sp1;      // wide path: K-steps per tap, K-steps of a tap that come from src1
     int dbg;                 // ablation bits (pfa_set_knob 1): 1 no output stores, 2 no stats, 4 no MFMA, 8 no DMA
+    // fused activation / BatchNorm backward on one output (dgrad launches): dy = act1'(y)*acc + act2'(y)*g2
+    int fuse_out, fuse_act1, fuse_act2;
+    const char* fuse_raw;
+    const char* fuse_g2;
+    const float *fuse_scale, *fuse_shift, *fuse_mean, *fuse_invstd;
+    int stat_col0, stat_n;   // statistics cover output columns [stat_col0, stat_col0 + stat_n), row length stat_n
 };
 
 template <typename T> struct Mma;
@@ -80,6 +86,16 @@ template <> __device__ __forceinline__ void store4<bf16_t>(char* p, const float*
 // STAGES == 3: ring of three buffers; the loads of K-step i+2 are issued while step i computes and are
 //              retired by a COUNTED s_waitcnt vmcnt + raw s_barrier, so a full K-step of DMA stays in
 //              flight across each barrier (cdna guide 5, "Pipelining across barriers").
+template <typename T> __device__ __forceinline__ void load4(const char* p, float* v);
+template <> __device__ __forceinline__ void load4<float>(const char* p, float* v) {
+    const f32x4 t = *(const f32x4*)p;
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+template <> __device__ __forceinline__ void load4<bf16_t>(const char* p, float* v) {
+    const bf16x4 t = *(const bf16x4*)p;
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
     constexpr int CH = ElemTraits<T>::CH;
@@ -253,50 +269,52 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
     const int lrow = lane & 15, kk = lane >> 4;
     // A K-step in three phases: (1) all 2*(FN+FM) fragment reads, (2) issue of the next tile's DMA (its address
     // arithmetic runs under the LDS latency), (3) the MFMAs, which the DMA then overlaps.
-    // Small per-wave tiles read both 64-byte halves of the K-step at once (one LDS latency per K-step); the 64x128
-    // per-wave tile of the 256x256 block would not fit its fragments twice and reads half by half.
+    // Fragments of one K-step: both 64-byte halves when they fit (64x64 per-wave tiles), else half by half.
     constexpr bool ALL_AT_ONCE = (FN + FM) <= 8;
     constexpr int NH = ALL_AT_ONCE ? 2 : 1;
-    typename Mma<T>::frag wf[NH][FN], af[NH][FM];
-    auto read_half = [&](int buf, int h, int slot) {
+    struct Frags {
+        typename Mma<T>::frag wf[NH][FN], af[NH][FM];
+    };
+    auto read_half = [&](Frags& f, int buf, int h, int slot) {
         const char* abase = smem + buf * STAGE;
         const char* wbase = abase + A_BYTES;
         const int ch = kk + 4 * h;
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int row = wn * TN + a * 16 + lrow;
-            wf[slot][a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            f.wf[slot][a] = *(const typename Mma<T>::frag*)(wbase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int row = wm * TM + b * 16 + lrow;
-            af[slot][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+            f.af[slot][b] = *(const typename Mma<T>::frag*)(abase + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
         }
     };
-    auto mfma_half = [&](int slot) {
+    auto mfma_half = [&](const Frags& f, int slot) {
 #pragma unroll
         for (int a = 0; a < FN; ++a)
 #pragma unroll
-            for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(wf[slot][a], af[slot][b], acc[a][b]);
+            for (int b = 0; b < FM; ++b) acc[a][b] = Mma<T>::run(f.wf[slot][a], f.af[slot][b], acc[a][b]);
     };
-    // phase 1: fragment reads; phase 2 (caller): issue of the next tile's DMA; phase 3: MFMAs under that DMA
+    Frags fA;
+    // 2-stage path, phase 1: fragment reads; phase 2 (caller): issue of the next tile's DMA; phase 3: MFMAs under that DMA
     auto read_frags = [&](int buf) {
         if (p.dbg & 4) return;
-        read_half(buf, 0, 0);
-        if constexpr (ALL_AT_ONCE) read_half(buf, 1, 1);
+        read_half(fA, buf, 0, 0);
+        if constexpr (ALL_AT_ONCE) read_half(fA, buf, 1, 1);
         __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead (the scheduler sinks them otherwise)
     };
     auto mfma_frags = [&](int buf) {
         if (p.dbg & 4) return;
         __builtin_amdgcn_sched_barrier(0);
-        mfma_half(0);
+        mfma_half(fA, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (ALL_AT_ONCE) {
-            mfma_half(1);
+            mfma_half(fA, 1);
         } else {
-            read_half(buf, 1, 0);
+            read_half(fA, buf, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_half(0);
+            mfma_half(fA, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -319,24 +337,62 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             mfma_frags(buf);
         }
     } else {
+        // Software-pipelined ring (3 LDS slots, two fragment register sets).  Step i:
+        //   issue DMA(i+2)  ->  MFMAs on half 0 of step i  ->  counted wait for DMA(i+1) + barrier  ->
+        //   issue every LDS read of step i+1 into the OTHER register set  ->  MFMAs on half 1 of step i.
+        // The LDS latency of step i+1 hides under half of step i's MFMAs, the DMA has 1.5 steps to land, and there is
+        // one barrier per step.  Slot (i+2)%3 held step i-1, whose reads every wave retired (lgkmcnt) before the
+        // barrier of step i-1; slot (i+1)%3 is read only after every wave's counted vmcnt + this step's barrier.
+        static_assert(ALL_AT_ONCE, "the pipelined ring needs both halves of a K-step in registers");
         const int nks = ks1 - ks0;
+        Frags fB;
         if (nks > 0) stage(ks0, 0);
         if (nks > 1) stage(ks0 + 1, 1);
-        int buf = 0;
-        for (int i = 0; i < nks; ++i) {
-            // retire step i's DMA but leave step i+1's in flight (this wave issued AROWS [+ WROWS] per step)
-            if (i + 1 < nks) {
-                if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
-                else PFA_WAIT_VMCNT(AROWS);
-            } else {
-                PFA_WAIT_VMCNT(0);
-            }
-            __builtin_amdgcn_s_barrier();   // every wave's step-i data is in LDS; everyone finished reading ring slot (i-1)%3
-            read_frags(buf);
-            if (i + 2 < nks) stage(ks0 + i + 2, buf == 0 ? 2 : buf - 1);
-            mfma_frags(buf);
-            buf = buf == 2 ? 0 : buf + 1;
+        if (nks > 1) {
+            if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
+            else PFA_WAIT_VMCNT(AROWS);
+        } else {
+            PFA_WAIT_VMCNT(0);
         }
+        __builtin_amdgcn_s_barrier();
+        if (nks > 0) { read_half(fA, 0, 0, 0); read_half(fA, 0, 1, 1); }
+        // steady state: no branch between the prefetch reads and the second MFMA half (a control-flow join there makes
+        // hipcc insert a full lgkmcnt(0), which would expose the prefetch latency again)
+        auto body_full = [&](int i, const Frags& cur, Frags& nxt) {
+            stage(ks0 + i + 2, (i + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(cur, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
+            else PFA_WAIT_VMCNT(AROWS);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of step i (both halves) have retired
+            __builtin_amdgcn_s_barrier();
+            read_half(nxt, (i + 1) % 3, 0, 0);
+            read_half(nxt, (i + 1) % 3, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_half(cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto body_tail = [&](int i, const Frags& cur, Frags& nxt) {      // last two steps: nothing left to stage
+            mfma_half(cur, 0);
+            if (i + 1 < nks) {
+                PFA_WAIT_VMCNT(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                read_half(nxt, (i + 1) % 3, 0, 0);
+                read_half(nxt, (i + 1) % 3, 1, 1);
+            }
+            mfma_half(cur, 1);
+        };
+        int i = 0;
+        for (; i + 3 < nks; i += 2) {       // both steps of the pair still have a tile to stage (i+2, i+3 < nks)
+            body_full(i, fA, fB);
+            body_full(i + 1, fB, fA);
+        }
+        // at most three steps remain; i is even, so the live fragment set is fA
+        if (i + 2 < nks) { body_full(i, fA, fB); body_tail(i + 1, fB, fA); body_tail(i + 2, fA, fB); }
+        else if (i + 1 < nks) { body_tail(i, fA, fB); body_tail(i + 1, fB, fA); }
+        else if (i < nks) { body_tail(i, fA, fB); }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -385,6 +441,48 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         }
     }
 
+    float fs[FN][4], fq[FN][4];        // per-lane partial statistics (filled by the fused backward, else from acc)
+    if (p.fuse_out) {
+        // This launch computes g = dL/d(act(y)) for the tensor `raw` (y = scale*raw + shift).  Turn it into
+        // dy = act1'(y)*g (+ act2'(y)*g2) right here and collect the BatchNorm-backward sums (dy, dy*xhat) per column:
+        // the separate elementwise pass over g, raw and dy disappears.
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+            const bool mine = p.fuse_out == 1 ? nbase < p.n1 : nbase >= p.n1;
+            const int col = p.fuse_out == 1 ? nbase : nbase - p.n1;
+            const int ld = p.fuse_out == 1 ? p.ld1 : p.ld2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fs[a][r] = 0.f; fq[a][r] = 0.f; }
+            if (!mine || col >= ld) continue;
+            float sc[4], sh[4], mu[4], is[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sc[r] = p.fuse_scale ? p.fuse_scale[col + r] : 1.f;
+                sh[r] = p.fuse_scale ? p.fuse_shift[col + r] : 0.f;
+                mu[r] = p.fuse_mean ? p.fuse_mean[col + r] : 0.f;
+                is[r] = p.fuse_mean ? p.fuse_invstd[col + r] : 1.f;
+            }
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                if (!mval[b]) continue;
+                const size_t e = opix[b] * ld + col;
+                float x[4], g2[4] = {0.f, 0.f, 0.f, 0.f};
+                load4<T>(p.fuse_raw + e * sizeof(T), x);
+                if (p.fuse_g2) load4<T>(p.fuse_g2 + e * sizeof(T), g2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y = x[r] * sc[r] + sh[r];
+                    float d = act_grad(y, p.fuse_act1, p.slope) * acc[a][b][r];
+                    if (p.fuse_g2) d += act_grad(y, p.fuse_act2, p.slope) * g2[r];
+                    acc[a][b][r] = d;
+                    fs[a][r] += d;
+                    fq[a][r] += d * ((x[r] - mu[r]) * is[r]);
+                }
+            }
+        }
+    }
+
     if (p.psum && !(p.dbg & 2)) {
         // per-column sums over this tile's rows (rows >= M are exact zeros: their operands were the zero page,
         // and BatchNorm layers carry no bias)
@@ -395,8 +493,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = 0.f, q = 0.f;
+                if (p.fuse_out) { s = fs[a][r]; q = fq[a][r]; }
+                else {
 #pragma unroll
-                for (int b = 0; b < FM; ++b) { const float v = acc[a][b][r]; s += v; q += v * v; }
+                    for (int b = 0; b < FM; ++b) { const float v = acc[a][b][r]; s += v; q += v * v; }
+                }
 #pragma unroll
                 for (int off = 1; off < 16; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
                 if (lrow == 0) {
@@ -407,13 +508,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < p.n) {
+        const int scol = n0 + tid - p.stat_col0;
+        if (tid < BN && scol >= 0 && scol < p.stat_n) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i) { s += red[i * BN + tid]; q += red[(WM + i) * BN + tid]; }
             const size_t trow = (size_t)cls * p.mtiles + mt;
-            p.psum[trow * p.n + n0 + tid] = s;
-            p.psq[trow * p.n + n0 + tid] = q;
+            p.psum[trow * p.stat_n + scol] = s;
+            p.psq[trow * p.stat_n + scol] = q;
         }
     }
 
@@ -597,9 +699,22 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.spt = k.wide ? k.ctot / kstep_ch : 1;
     k.sp1 = k.wide ? a->c1 / kstep_ch : 1;
     k.dbg = g_knob[1];
+    k.fuse_out = a->fuse_out; k.fuse_act1 = a->fuse_act1; k.fuse_act2 = a->fuse_act2;
+    k.fuse_raw = (const char*)a->fuse_raw; k.fuse_g2 = (const char*)a->fuse_g2;
+    k.fuse_scale = a->fuse_scale; k.fuse_shift = a->fuse_shift; k.fuse_mean = a->fuse_mean; k.fuse_invstd = a->fuse_invstd;
+    k.stat_col0 = 0; k.stat_n = a->n;
+    if (a->fuse_out) {
+        PFA_REQUIRE(a->fuse_out == 1 || (a->fuse_out == 2 && a->ld2 > 0), "pfa_gather_gemm: fuse_out must name an existing output");
+        PFA_REQUIRE(a->fuse_raw && (a->fuse_scale == nullptr) == (a->fuse_shift == nullptr) &&
+                    (a->fuse_mean == nullptr) == (a->fuse_invstd == nullptr), "pfa_gather_gemm: incomplete fused-backward arguments");
+        PFA_REQUIRE(a->bias == nullptr && a->act == PFA_ACT_NONE, "pfa_gather_gemm: fused backward excludes bias/activation");
+        k.stat_col0 = a->fuse_out == 1 ? 0 : a->n1;
+        k.stat_n = a->fuse_out == 1 ? a->ld1 : a->ld2;
+    }
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of splitk*pixels*round4(n) floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
+    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1), "pfa_gather_gemm: the fused backward epilogue cannot be combined with split-K");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
     if (a->mode == PFA_CONV_S1) PFA_REQUIRE(a->hs == a->hq + 1 && a->ws == a->wq + 1, "pfa_gather_gemm: CONV_S1 needs hs=hq+1");
@@ -723,6 +838,8 @@ extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int
 extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
+    PFA_REQUIRE(!a->fuse_out || (a->fuse_mean != nullptr) == (a->psum != nullptr),
+                "pfa_gather_gemm: a fused BatchNorm backward needs psum/psq, a fused activation backward must not pass them");
     hipStream_t st = (hipStream_t)s;
     const TileCfg cfg = choose_cfg(k);
     int rc;

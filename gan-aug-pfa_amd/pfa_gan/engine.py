@@ -261,6 +261,30 @@ class _Engine:
         K.bn_bwd_apply(dy, raw, coef, dy)
         return dy
 
+    def _fuse_spec(self, L, ctx, tag, out, raw, act1, g2=None, act2=K.ACT_NONE):
+        """gather_gemm(fuse=...) for the node 'conv output of layer L' (raw = its stored output; without a norm the
+        activated output stands in: sign(act(x)) == sign(x))."""
+        spec = dict(out=out, raw=raw, act1=act1, g2=g2, act2=act2)
+        if L.bn is not None:
+            f32, c = torch.float32, L.cout
+            spec.update(scale=ctx.buf(tag + ".scale", (c,), f32), shift=ctx.buf(tag + ".shift", (c,), f32),
+                        mean=ctx.buf(tag + ".mean", (c,), f32), invstd=ctx.buf(tag + ".invstd", (c,), f32))
+        return spec
+
+    def _finish_fused(self, L, ctx, tag, raw, count, garena, dy, st, param_grads=True):
+        """Second half of the BatchNorm backward after a fused dgrad epilogue wrote dy and the partial sums."""
+        if L.bn is None:
+            return dy
+        part, _, nt = st
+        f32, c = torch.float32, L.cout
+        coef = ctx.buf(tag + ".coef", (3 * c,), f32)
+        dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
+        dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
+        K.bn_bwd_finalize(part, nt, c, count, L.bn.weight, ctx.buf(tag + ".mean", (c,), f32),
+                          ctx.buf(tag + ".invstd", (c,), f32), dgamma, dbeta, coef)
+        K.bn_bwd_apply(dy, raw, coef, dy)
+        return dy
+
     def _act_backward(self, ctx, tag, act_out, g1, act1, g2=None, act2=K.ACT_NONE):
         """Conv output without a norm: its gradient is act'(.)*g, and sign(act_out) == sign(pre-activation)."""
         dr = ctx.buf(tag + ".dy", act_out.shape, act_out.dtype)
@@ -358,26 +382,49 @@ class GeneratorEngine(_Engine):
         v = ctx.v
         B, H, W, _ = v["x"].shape
         g_skip, g_up = {}, {}
+        ready = {}          # node tag -> conv-output gradient already produced by a fused dgrad epilogue
         # ---- decoder, outermost first
         d = dpre
         for k in range(D):
             L = self.up[k]
             h, w = H >> (k + 1), W >> (k + 1)            # input grid of this transposed conv
             if k > 0:
-                raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
-                d = self._bn_backward(L, ctx, f"u{k}", raw, B * 4 * h * w, garena, g_up[k], K.ACT_RELU)
+                if f"u{k}" in ready:
+                    d = ready.pop(f"u{k}")
+                else:
+                    raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
+                    d = self._bn_backward(L, ctx, f"u{k}", raw, B * 4 * h * w, garena, g_up[k], K.ACT_RELU)
             srcs = [v["aR"][k]] if k == D - 1 else [v["aR"][k], v["uR"][k + 1]]
+
             def pg(ws, L=L, srcs=srcs, d=d):
                 K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=ws)
                 if L.b is not None:
                     K.colsum(d, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
+            fusable = K.auto_splitk(K.CONV_S2, [d], L.conv.in_channels, (B, h, w)) == 1
+            if k == D - 1:
+                # the only consumer of the innermost conv output is this ReLU: its gradient is final here
+                Ln = self.down[k]
+                if fusable:
+                    dr = ctx.buf(f"e{k}.dy", srcs[0].shape, dt)
+                    K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [dr], (B, h, w), self.ws,
+                                  fuse=self._fuse_spec(Ln, ctx, f"e{k}", 1, v["aR"][k], K.ACT_RELU))
+                    ready[f"e{k}"] = dr
+                else:
+                    g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
+                    K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k]], (B, h, w), self.ws)
+                continue
             g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
-            outs = [g_skip[k]]
-            if k < D - 1:
+            Ln = self.up[k + 1]
+            if fusable:
+                dyn = ctx.buf(f"u{k + 1}.dy", srcs[1].shape, dt)
+                rawn = ctx.buf(f"u{k + 1}.raw", srcs[1].shape, dt)
+                st = K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], dyn], (B, h, w), self.ws,
+                                   fuse=self._fuse_spec(Ln, ctx, f"u{k + 1}", 2, rawn, K.ACT_RELU))
+                ready[f"u{k + 1}"] = self._finish_fused(Ln, ctx, f"u{k + 1}", rawn, B * h * w, garena, dyn, st)
+            else:
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
-                outs.append(g_up[k + 1])
-            K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, outs, (B, h, w), self.ws)
+                K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], g_up[k + 1]], (B, h, w), self.ws)
         mid_level = self.grad_buckets()[1]
         if bucket_ready is not None:
             bucket_ready(0)
@@ -386,7 +433,9 @@ class GeneratorEngine(_Engine):
         for k in range(D - 1, -1, -1):
             L = self.down[k]
             h, w = H >> (k + 1), W >> (k + 1)
-            if k == D - 1:
+            if f"e{k}" in ready:
+                dr = ready.pop(f"e{k}")
+            elif k == D - 1:
                 dr = self._act_backward(ctx, f"e{k}", v["aR"][k], g_skip[k], K.ACT_RELU)
             elif L.bn is None:
                 dr = self._act_backward(ctx, f"e{k}", v["aL"][k], g_down, K.ACT_LRELU, g_skip[k], K.ACT_RELU)
@@ -395,6 +444,7 @@ class GeneratorEngine(_Engine):
                 dr = self._bn_backward(L, ctx, f"e{k}", raw, B * h * w, garena, g_down, K.ACT_LRELU, g_skip[k],
                                        K.ACT_RELU)
             src = v["x"] if k == 0 else v["aL"][k - 1]
+
             def pg(ws, L=L, dr=dr, src=src):
                 K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=ws)
                 if L.b is not None:
@@ -403,8 +453,18 @@ class GeneratorEngine(_Engine):
             if bucket_ready is not None and k == mid_level and k > 0:
                 bucket_ready(1)
             if k > 0:
-                g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
-                K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
+                Lp = self.down[k - 1]             # the node this input gradient belongs to
+                hp, wp = H >> k, W >> k
+                if K.auto_splitk(K.TCONV_S2, [dr], src.shape[3], (B, h, w)) == 1:
+                    rawp = ctx.buf(f"e{k - 1}.raw", src.shape, dt) if Lp.bn is not None else v["aL"][k - 1]
+                    dyp = ctx.buf(f"e{k - 1}.dy", src.shape, dt)
+                    st = K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [dyp], (B, h, w), self.ws,
+                                       fuse=self._fuse_spec(Lp, ctx, f"e{k - 1}", 1, rawp, K.ACT_LRELU, g_skip[k - 1],
+                                                            K.ACT_RELU))
+                    ready[f"e{k - 1}"] = self._finish_fused(Lp, ctx, f"e{k - 1}", rawp, B * hp * wp, garena, dyp, st)
+                else:
+                    g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
+                    K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
         if bucket_ready is not None:
             bucket_ready(2 if mid_level > 0 else 1)
 
@@ -486,12 +546,15 @@ class DiscriminatorEngine(_Engine):
         n = len(self.layers)
         g = dlogits
         dx = None
+        ready = None        # conv-output gradient of layer i already produced by the fused epilogue of layer i+1's dgrad
         for i in range(n - 1, -1, -1):
             L = self.layers[i]
             out = v["a"][i]
             B, ho, wo, _ = out.shape
             if i == n - 1:
                 dr = g
+            elif ready is not None:
+                dr, ready = ready, None
             elif L.bn is None:
                 dr = self._act_backward(ctx, f"c{i}", out, g, K.ACT_LRELU)
             else:
@@ -508,11 +571,21 @@ class DiscriminatorEngine(_Engine):
             if i > 0 or need_dx:
                 hin, win = inputs[0].shape[1:3]
                 cp = sum(L.in_pad)
-                g = ctx.buf(f"g.c{i}", (B, hin, win, cp), dt)
-                if L.stride == 2:
-                    K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, cp, [g], (B, ho, wo), self.ws_cur)
+                mode = K.TCONV_S2 if L.stride == 2 else K.CONV_S1_DGRAD
+                grid = (B, ho, wo) if L.stride == 2 else (B, hin, win)
+                if i > 0 and K.auto_splitk(mode, [dr], cp, grid) == 1:
+                    Lp = self.layers[i - 1]
+                    prev = v["a"][i - 1]
+                    rawp = ctx.buf(f"c{i - 1}.raw", prev.shape, dt) if Lp.bn is not None else prev
+                    dyp = ctx.buf(f"c{i - 1}.dy", prev.shape, dt)
+                    st = K.gather_gemm(mode, [dr], L.w_bwd, cp, [dyp], grid, self.ws_cur,
+                                       fuse=self._fuse_spec(Lp, ctx, f"c{i - 1}", 1, rawp, K.ACT_LRELU))
+                    hp, wp = prev.shape[1:3]
+                    ready = self._finish_fused(Lp, ctx, f"c{i - 1}", rawp, B * hp * wp, garena, dyp, st,
+                                               param_grads=param_grads)
                 else:
-                    K.gather_gemm(K.CONV_S1_DGRAD, [dr], L.w_bwd, cp, [g], (B, hin, win), self.ws_cur)
-                if i == 0:
-                    dx = g
+                    g = ctx.buf(f"g.c{i}", (B, hin, win, cp), dt)
+                    K.gather_gemm(mode, [dr], L.w_bwd, cp, [g], grid, self.ws_cur)
+                    if i == 0:
+                        dx = g
         return dx

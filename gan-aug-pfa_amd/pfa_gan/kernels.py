@@ -82,10 +82,23 @@ def choose_splitk(mode, M, n, ctot, dtype):
     return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
 
 
-def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None):
+import os as _os
+FUSE_BWD = _os.environ.get("PFA_FUSE_BWD", "1") != "0"     # A/B switch for the fused dgrad epilogue
+
+
+def auto_splitk(mode, srcs, n, grid):
+    if not FUSE_BWD:
+        return 0            # "not 1": callers fall back to the separate backward-reduce pass
+    return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(s.shape[3] for s in srcs), srcs[0].dtype)
+
+
+def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None):
     """out = act(bias + implicit_gemm(srcs, w)).  srcs/outs: lists of 1 or 2 NHWC tensors.
 
     grid = (nb, hq, wq) position grid.  Returns (psum, psq, ntiles) views when stats=True.
+    fuse: dict(out=1|2, raw=, act1=, g2=None, act2=, scale=, shift=, mean=, invstd=) - the named output receives
+    dy = act1'(y)*g + act2'(y)*g2 (activation / BatchNorm backward fused into this input-gradient launch); with
+    mean/invstd the call returns (part, None, ntiles) for bn_bwd_finalize.
     """
     _require_cuda(*srcs, w, *outs)
     dtype = srcs[0].dtype
@@ -110,6 +123,20 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     if a.splitk > 1:
         a.slab = ptr(ws.get("slab", a.splitk * npix * ((n + 3) // 4 * 4)))
     psum = psq = None
+    if fuse is not None:
+        a.fuse_out, a.fuse_act1, a.fuse_act2 = fuse["out"], fuse["act1"], fuse.get("act2", ACT_NONE)
+        a.fuse_raw, a.fuse_g2 = ptr(fuse["raw"]), ptr(fuse.get("g2"))
+        a.fuse_scale, a.fuse_shift = ptr(fuse.get("scale")), ptr(fuse.get("shift"))
+        a.fuse_mean, a.fuse_invstd = ptr(fuse.get("mean")), ptr(fuse.get("invstd"))
+        if fuse.get("mean") is not None:
+            tiles = lib().pfa_gather_stat_tiles(ctypes.byref(a))
+            if tiles < 0:
+                check(tiles, "pfa_gather_stat_tiles")
+            c = outs[fuse["out"] - 1].shape[3]
+            part = ws.get("bwdpart", 2 * tiles * c)
+            a.psum, a.psq = ptr(part), part.data_ptr() + 4 * tiles * c
+            check(lib().pfa_gather_gemm(ctypes.byref(a), stream()), "pfa_gather_gemm")
+            return part, None, a.ntiles_stat
     if stats:
         tiles = lib().pfa_gather_stat_tiles(ctypes.byref(a))
         if tiles < 0:

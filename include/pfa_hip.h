@@ -84,6 +84,19 @@ typedef struct pfa_gather_args {
     float* psum;                 /* optional BatchNorm partial sums   [tiles][n]    */
     float* psq;                  /* optional partial sums of squares  [tiles][n]    */
     float* slab;                 /* splitk>1: float32 [splitk][pixels][round4(n)] workspace */
+    /* Fused activation / BatchNorm backward (input-gradient launches, splitk == 1, no bias/act): the chosen output
+     * receives dy = act1'(y)*g + act2'(y)*g2 instead of g, with y = scale*raw + shift (scale NULL: y = raw) and raw the
+     * conv output that output is the gradient of (same shape).  With mean/invstd, psum/psq receive the per-tile
+     * sums of dy and dy*xhat over the fused output's columns (row length = its ld) for pfa_bn_bwd_finalize. */
+    int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2                                  */
+    int32_t fuse_act1, fuse_act2;
+    int32_t reserved;
+    const void* fuse_raw;
+    const void* fuse_g2;         /* optional second gradient w.r.t. the same tensor              */
+    const float* fuse_scale;
+    const float* fuse_shift;
+    const float* fuse_mean;
+    const float* fuse_invstd;
 } pfa_gather_args;
 
 /* Tiles of partial statistics a call will write (rows of psum/psq) for this geometry. */
