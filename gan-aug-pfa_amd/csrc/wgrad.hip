@@ -75,10 +75,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     const int mend = min(p.M, mbeg + p.mper);
     const char* zero = (const char*)g_pfa_zero_page;
 
-    // swizzle of the chunk index inside a tile row (applied on the DMA source and on the reads)
+    // swizzle of the chunk index inside a tile row (applied on the DMA source and on the reads).  A transpose read
+    // touches, per 32-lane half, rows {r..r+3, r+8..r+11} x 32 B: row bits 0,1,3 must select distinct 32-byte
+    // segments of the 256-byte bank row (bit 2 only moves inside the segment).
     auto swz = [](int row, int rc) -> int {
         if (rc < 16) return 0;
-        return BF ? (row & 15) : ((row & 1) << 2);
+        return BF ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row & 1) << 2);
     };
 
     // ---- direct operand: this thread's chunk column is fixed for the whole kernel
