@@ -6,7 +6,7 @@ G fwd, 3x D fwd, both backwards, both Adam updates) at 256x256x3, batch 16 per G
 
 One JSON line on rank 0.  `value` = N * batch * K / (max over ranks of the timed K steps), inputs resident in
 HBM (a pool of pre-packed synthetic batches, seed 1234 + rank).  Extra objects:
-  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,128,128,2,2>): HIP-event
+  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,128,128,2,2,2>): HIP-event
                 time of every launch of it over a pass of the same steps, against its algorithmic conv FLOPs
                 (2 * pixels * Cout * taps * Cin_real per launch; SURVEY 8d counts the same MACs)
   cpu_baseline  the numpy oracle's gan_step (oracle/step.py, "port") on the host cores, bounded sample
@@ -105,7 +105,7 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                 traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes_per_launch=round(sum(alg_bytes) / max(len(alg_bytes), 1)),
-                kernel=f"k_gather_gemm<{precision},128,128,2,2>", launches_per_step=len(rec) // steps,
+                kernel=f"k_gather_gemm<{precision},128,128,2,2,2>", launches_per_step=len(rec) // steps,
                 avg_launch_us=round(1e3 * ms / len(rec), 2), flop_per_launch=round(flops / len(rec)),
                 flop_share_of_step=round(flops / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3))
 
@@ -181,11 +181,19 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} "
                              f"bench.py ...` (one process per GPU)")
         args.gpus = world
+    # Rehearsal of the N-rank control flow on a one-GPU box (tests/test_gpu_networks.py): PFA_BENCH_BACKEND=gloo with
+    # PFA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and reduces through gloo.  The measured configuration is RCCL.
+    backend = os.environ.get("PFA_BENCH_BACKEND", "nccl")
+    if os.environ.get("PFA_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     import pfa_gan
@@ -231,6 +239,8 @@ def main():
     assert all(l == l and abs(l) < 1e6 for l in losses), f"non-finite loss {losses}"
     assert _lib.launch_count() > launches0
 
+    # every rank takes part in the roofline pass: its steps carry the same gradient all-reduces as the timed ones
+    roof = None if args.no_roofline else kernel_roofline(trainer, *pool[0], max(2, min(args.steps, 5)), args.precision)
     if rank == 0:
         pairs = world * args.batch * args.steps
         value = pairs / dt
@@ -245,14 +255,14 @@ def main():
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph x3 segments" if args.graph else
-                                 ("eager, 2 HIP streams" if not args.no_overlap else "eager, 1 HIP stream"),
+                                 ("eager, 3 HIP streams" if not args.no_overlap else "eager, 1 HIP stream"),
                        "last_losses": [round(l, 4) for l in losses]},
         }
         if flop_pair:
             tf = value * flop_pair / 1e12 / world
             out["step_mfma"] = {"algorithmic_tflops_per_gpu": round(tf, 2), "frac_of_peak": round(tf / peak, 4)}
-        if not args.no_roofline:
-            out["roofline"] = kernel_roofline(trainer, *pool[0], max(2, min(args.steps, 5)), args.precision)
+        if roof is not None:
+            out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.size == 256:
             out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_steps)
         print(json.dumps(out), flush=True)

@@ -80,12 +80,34 @@ template <> __device__ __forceinline__ void store4<bf16_t>(char* p, const float*
     *(bf16x4*)p = t;
 }
 
-#define PFA_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-// STAGES == 2: two LDS buffers, __syncthreads() per K-step (drains the DMA queue at every barrier).
-// STAGES == 3: ring of three buffers; the loads of K-step i+2 are issued while step i computes and are
-//              retired by a COUNTED s_waitcnt vmcnt + raw s_barrier, so a full K-step of DMA stays in
-//              flight across each barrier (cdna guide 5, "Pipelining across barriers").
+#define PFA_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+
+// LDS fragment read that hipcc cannot see through.  The compiler drains vmcnt before any LDS read that may alias an
+// LDS-DMA in flight - with one dynamic LDS array that is every read - which would serialise the next tile's DMA behind
+// this tile's reads.  Reads issued this way are retired by an explicit PFA_WAIT_LGKM followed by pin() on each
+// destination (the empty asm makes every later use of the value depend on the wait).
+template <typename F, int OFF> __device__ __forceinline__ F lds_read16(unsigned addr) {
+    static_assert(sizeof(F) == 16 && OFF >= 0 && OFF < 65536, "fragment size / ds offset field");
+    F v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// N fragments 16 tile rows (2048 bytes) apart from one address register
+template <typename F, int N, int I = 0> struct ReadFrags {
+    static __device__ __forceinline__ void run(F* dst, unsigned addr) {
+        if constexpr (I < N) {
+            dst[I] = lds_read16<F, I * 2048>(addr);
+            ReadFrags<F, N, I + 1>::run(dst, addr);
+        }
+    }
+};
+template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
+
+// EARLY == 0: K-step = fragment reads -> issue of the next tile's DMA -> MFMAs (the DMA overlaps the MFMAs only).
+// EARLY == 1: K-step = issue of the next tile's DMA -> fragment reads (lds_read16) -> MFMAs: the DMA is in flight
+//             for the whole step (cdna guide T3/T4 "minimum 2-phase": stage before the reads, one barrier per tile).
+// EARLY == 2: as 1, with the DMA pieces issued between the MFMAs of the first half (see the loop).
 template <typename T> __device__ __forceinline__ void load4(const char* p, float* v);
 template <> __device__ __forceinline__ void load4<float>(const char* p, float* v) {
     const f32x4 t = *(const f32x4*)p;
@@ -96,8 +118,8 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const char* p, float* 
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
+template <typename T, int BM, int BN, int WM, int WN, int EARLY>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2))) void k_gather_gemm(const GatherK p) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int NT = 64 * WM * WN;                       // threads
     constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -229,30 +251,35 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         }
         seg_left = (seg_part ? p.spt - p.sp1 : p.sp1) - kc;
     };
-    auto stage_wide = [&](int buf) {
+    // piece j of a wide stage: activation row pass j (j < AROWS) or weight row pass j - AROWS
+    auto stage_wide_piece = [&](int buf, int j) {
         char* abase = smem + buf * STAGE;
         char* wbase = abase + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AROWS; ++i) {
+        if (j < AROWS) {
+            const int i = j;
             const bool ok = (okmask >> i) & 1u;
             const char* gp = ok ? seg_base + a_off[i] : zero;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
             a_off[i] += 128u;
+        } else if (wave < WWAVES) {
+            const int i = j - AROWS;
+            const bool ok = (okmask >> (16 + i)) & 1u;
+            const char* gp = ok ? p.w + w_off[i] : zero;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+            w_off[i] += 128u;
         }
-        if (wave < WWAVES) {
-#pragma unroll
-            for (int i = 0; i < WROWS; ++i) {
-                const bool ok = (okmask >> (16 + i)) & 1u;
-                const char* gp = ok ? p.w + w_off[i] : zero;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wbase + (i * NT + wave * 64) * 16), 16, 0, 0);
-                w_off[i] += 128u;
-            }
-        }
+    };
+    auto stage_wide_next = [&]() {
         if (--seg_left == 0) {          // next segment: the other source of this tap, or the next tap
             if (seg_part == 0 && p.sp1 < p.spt) seg_part = 1;
             else { seg_part = 0; ++seg_tap; }
             seg_setup(0);               // (one harmless setup past the last tap: pointers are never used)
         }
+    };
+    auto stage_wide = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AROWS + WROWS; ++j) stage_wide_piece(buf, j);
+        stage_wide_next();
     };
     auto stage = [&](int ks, int buf) {
         if (p.dbg & 8) return;
@@ -327,7 +354,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
         seg_part = within >= p.sp1 ? 1 : 0;
         seg_setup(seg_part ? within - p.sp1 : within);
     }
-    if constexpr (STAGES == 2) {
+    if constexpr (!EARLY) {
         if (ks0 < ks1) stage(ks0, 0);
         for (int ks = ks0; ks < ks1; ++ks) {
             const int buf = (ks - ks0) & 1;
@@ -337,62 +364,94 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gather_gemm(const GatherK p) {
             mfma_frags(buf);
         }
     } else {
-        // Software-pipelined ring (3 LDS slots, two fragment register sets).  Step i:
-        //   issue DMA(i+2)  ->  MFMAs on half 0 of step i  ->  counted wait for DMA(i+1) + barrier  ->
-        //   issue every LDS read of step i+1 into the OTHER register set  ->  MFMAs on half 1 of step i.
-        // The LDS latency of step i+1 hides under half of step i's MFMAs, the DMA has 1.5 steps to land, and there is
-        // one barrier per step.  Slot (i+2)%3 held step i-1, whose reads every wave retired (lgkmcnt) before the
-        // barrier of step i-1; slot (i+1)%3 is read only after every wave's counted vmcnt + this step's barrier.
-        static_assert(ALL_AT_ONCE, "the pipelined ring needs both halves of a K-step in registers");
-        const int nks = ks1 - ks0;
-        Frags fB;
-        if (nks > 0) stage(ks0, 0);
-        if (nks > 1) stage(ks0 + 1, 1);
-        if (nks > 1) {
-            if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
-            else PFA_WAIT_VMCNT(AROWS);
-        } else {
-            PFA_WAIT_VMCNT(0);
+        // per-lane byte offsets of this wave's first weight / activation fragment inside a stage, per 64-byte half; the
+        // other fragments sit 16 rows = 2048 bytes further on (the swizzle term depends on row & 15 only)
+        typedef typename Mma<T>::frag frag_t;
+        const unsigned sw = (lrow >> 1) & 7;
+        const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+        unsigned wfb[2], afb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            wfb[h] = lds0 + A_BYTES + (wn * TN + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
+            afb[h] = lds0 + (wm * TM + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
         }
-        __builtin_amdgcn_s_barrier();
-        if (nks > 0) { read_half(fA, 0, 0, 0); read_half(fA, 0, 1, 1); }
-        // steady state: no branch between the prefetch reads and the second MFMA half (a control-flow join there makes
-        // hipcc insert a full lgkmcnt(0), which would expose the prefetch latency again)
-        auto body_full = [&](int i, const Frags& cur, Frags& nxt) {
-            stage(ks0 + i + 2, (i + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_half(cur, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (wave < WWAVES) PFA_WAIT_VMCNT(AROWS + WROWS);
-            else PFA_WAIT_VMCNT(AROWS);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of step i (both halves) have retired
-            __builtin_amdgcn_s_barrier();
-            read_half(nxt, (i + 1) % 3, 0, 0);
-            read_half(nxt, (i + 1) % 3, 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_half(cur, 1);
-            __builtin_amdgcn_sched_barrier(0);
+        auto read_half_raw = [&](Frags& f, int buf, int h, int slot) {
+            ReadFrags<frag_t, FN>::run(f.wf[slot], wfb[h] + buf * STAGE);
+            ReadFrags<frag_t, FM>::run(f.af[slot], afb[h] + buf * STAGE);
         };
-        auto body_tail = [&](int i, const Frags& cur, Frags& nxt) {      // last two steps: nothing left to stage
-            mfma_half(cur, 0);
-            if (i + 1 < nks) {
-                PFA_WAIT_VMCNT(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                read_half(nxt, (i + 1) % 3, 0, 0);
-                read_half(nxt, (i + 1) % 3, 1, 1);
+        auto pin_half = [&](Frags& f, int slot) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a) pin(f.wf[slot][a]);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) pin(f.af[slot][b]);
+        };
+        if (ks0 < ks1) stage(ks0, 0);
+        // EARLY == 2 (wide staging, both halves in registers): the DMA pieces of the next tile are spread over the
+        // MFMAs of the first half instead of being issued in one burst - a wave stalls on each global_load_lds while
+        // the CU's address unit drains the queue (that stall, not the landing, is what serialised DMA and MFMA).
+        constexpr int NPIECE = AROWS + WROWS, MF0 = FN * FM;
+        constexpr bool CAN_SPREAD = EARLY == 2 && ALL_AT_ONCE && MF0 >= NPIECE && MF0 % NPIECE == 0;
+        const bool wide_ok = CAN_SPREAD && p.wide && !(p.dbg & 8);
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int buf = (ks - ks0) & 1;
+            // stage ks has landed (vmcnt(0)); every wave retired its reads of buf^1 (PFA_WAIT_LGKM) before its MFMAs of
+            // step ks-1, i.e. before arriving here, so the DMA below may overwrite buf^1 at once
+            __syncthreads();
+            const bool more = ks + 1 < ks1;
+            if constexpr (CAN_SPREAD) {
+                const bool sp = more && wide_ok;
+                if (more && !wide_ok) stage(ks + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_half_raw(fA, buf, 0, 0);
+                read_half_raw(fA, buf, 1, 1);
+                PFA_WAIT_LGKM(FN + FM);
+                pin_half(fA, 0);
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) {
+                        acc[a][b] = Mma<T>::run(fA.wf[0][a], fA.af[0][b], acc[a][b]);
+                        constexpr int PER = MF0 / NPIECE;
+                        if ((a * FM + b) % PER == PER - 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (sp) stage_wide_piece(buf ^ 1, (a * FM + b) / PER);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                if (sp) stage_wide_next();
+                __builtin_amdgcn_sched_barrier(0);
+                PFA_WAIT_LGKM(0);
+                pin_half(fA, 1);
+                mfma_half(fA, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (more) stage(ks + 1, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(p.dbg & 4)) {
+                    read_half_raw(fA, buf, 0, 0);
+                    if constexpr (ALL_AT_ONCE) {
+                        read_half_raw(fA, buf, 1, 1);
+                        PFA_WAIT_LGKM(FN + FM);          // LDS reads return in order: the first half is here
+                        pin_half(fA, 0);
+                        mfma_half(fA, 0);
+                        __builtin_amdgcn_sched_barrier(0);   // keep these MFMAs ahead of the second wait
+                        PFA_WAIT_LGKM(0);
+                        pin_half(fA, 1);
+                        mfma_half(fA, 1);
+                    } else {
+                        PFA_WAIT_LGKM(0);
+                        pin_half(fA, 0);
+                        mfma_half(fA, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_half_raw(fA, buf, 1, 0);
+                        PFA_WAIT_LGKM(0);
+                        pin_half(fA, 0);
+                        mfma_half(fA, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            mfma_half(cur, 1);
-        };
-        int i = 0;
-        for (; i + 3 < nks; i += 2) {       // both steps of the pair still have a tile to stage (i+2, i+3 < nks)
-            body_full(i, fA, fB);
-            body_full(i + 1, fB, fA);
         }
-        // at most three steps remain; i is even, so the live fragment set is fA
-        if (i + 2 < nks) { body_full(i, fA, fB); body_tail(i + 1, fB, fA); body_tail(i + 2, fA, fB); }
-        else if (i + 1 < nks) { body_tail(i, fA, fB); body_tail(i + 1, fB, fA); }
-        else if (i < nks) { body_tail(i, fA, fB); }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -724,25 +783,20 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 }
 
 // ---- tile configuration
-// id 0: 128x128, 4 waves, 2 stages   id 1: 128x64, 4 waves, 2 stages   id 2: 256x16, 4 waves, 2 stages
-// id 3: 128x128, 4 waves, 3-stage ring   id 4: 256x128, 8 waves, 3-stage ring
-// id 5: 256x128, 8 waves, 2 stages        id 6: 256x256, 8 waves, 2 stages (128 KiB LDS, one workgroup per CU)
+// shape 0: 128x128, 4 waves   shape 1: 128x64, 4 waves   shape 2: 256x16, 4 waves   shape 3: 256x128, 8 waves
+// (two LDS buffers each).  pfa_set_knob(0, v): v = 4 forces shape 3 on launches with n >= 128, anything else is the
+// automatic choice.  pfa_set_knob(2, v): K-loop variant, 0 = default, v = 1..3 selects EARLY = v - 1.
 struct TileCfg { int id, bm, bn; };
+constexpr int DEFAULT_EARLY = 2;
 
 inline TileCfg choose_cfg(const GatherK& k) {
-    const int classes = k.mode == PFA_TCONV_S2 ? 4 : 1;
-    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 128, 128}, {4, 256, 128},
-                                   {5, 256, 128}, {6, 256, 256}};
+    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 256, 128}};
     if (k.n <= 16) return cfgs[2];
     if (k.n <= 64) return cfgs[1];
-    if (g_knob[0] >= 1 && g_knob[0] <= 7 && cfgs[g_knob[0] - 1].bn >= 128) {
-        const TileCfg c = cfgs[g_knob[0] - 1];
-        if (c.bn == 128 || k.n >= 256) return c;        // the 256-wide tile only where it is filled
-    }
     // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
-    (void)classes;
+    if (g_knob[0] == 4) return cfgs[3];
     return cfgs[0];
 }
 
@@ -759,34 +813,39 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     return classes * ((k.M + bm - 1) / bm);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+template <typename T, int BM, int BN, int WM, int WN, int EARLY>
 static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.mtiles = (k.M + BM - 1) / BM;
     k.ntiles = (k.n + BN - 1) / BN;
     k.nwg = k.mtiles * k.ntiles * classes * k.splitk;
     dim3 grid(k.nwg);
-    const size_t lds = STAGES * (BM * 128 + BN * 128);
+    const size_t lds = 2 * (BM * 128 + BN * 128);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, STAGES>,
+        (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, EARLY>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN, STAGES>), grid, dim3(64 * WM * WN), lds, st, k);
+    hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN, EARLY>), grid, dim3(64 * WM * WN), lds, st, k);
     PFA_LAUNCHED("k_gather_gemm");
     return 0;
 }
 
 template <typename T>
 static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t st) {
-    switch (cfg) {
-        case 0: return launch_gather<T, 128, 128, 2, 2, 2>(k, classes, st);
-        case 1: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
-        case 2: return launch_gather<T, 256, 16, 4, 1, 2>(k, classes, st);
-        case 3: return launch_gather<T, 128, 128, 2, 2, 3>(k, classes, st);
-        case 4: return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
-        case 5: return launch_gather<T, 256, 128, 4, 2, 2>(k, classes, st);
-        default: return launch_gather<T, 256, 256, 4, 2, 2>(k, classes, st);
+    const int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : DEFAULT_EARLY;
+    switch (cfg * 3 + early) {
+        case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
+        case 1: return launch_gather<T, 128, 128, 2, 2, 1>(k, classes, st);
+        case 2: return launch_gather<T, 128, 128, 2, 2, 2>(k, classes, st);
+        case 3: return launch_gather<T, 128, 64, 2, 2, 0>(k, classes, st);
+        case 4: return launch_gather<T, 128, 64, 2, 2, 1>(k, classes, st);
+        case 5: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
+        case 6: return launch_gather<T, 256, 16, 4, 1, 0>(k, classes, st);
+        case 7: case 8: return launch_gather<T, 256, 16, 4, 1, 1>(k, classes, st);
+        case 9: return launch_gather<T, 256, 128, 4, 2, 0>(k, classes, st);
+        case 10: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
+        default: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
     }
 }
 

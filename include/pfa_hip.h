@@ -50,8 +50,9 @@ const char* pfa_last_error_string(void);
 /* Number of kernel launches issued by this process through the library (tests use it to
  * prove the HIP path, not a fallback, produced a result). */
 uint64_t pfa_launch_count(void);
-/* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: force a gather tile
- * configuration (1..5), 0 = automatic. */
+/* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: gather tile (0 = automatic,
+ * 4 = 256x128 where n >= 128); id 1: in-kernel ablation bits (1 no stores, 2 no statistics, 4 no MFMA, 8 no DMA);
+ * id 2: gather K-loop (0 = default, 1 = fragment reads before the next tile's DMA, 2 = DMA first). */
 int pfa_set_knob(int id, int value);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA

@@ -329,3 +329,42 @@ def test_full_size_step_vs_oracle(precision, n, h):
     assert int(D.state_dict()["model.3.num_batches_tracked"]) == 3
     for t in list(G.state_dict().values()) + list(D.state_dict().values()):
         assert torch.isfinite(t.float()).all()
+
+
+def _torchrun(script_args, env_extra, timeout=600):
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"], ids=["three-streams", "one-stream"])
+def test_data_parallel_two_ranks_on_device(overlap):
+    """Two ranks, device tensors, the HIP engine: parameters stay identical across ranks and equal the single-process
+    update from the mean gradient (tests/dp_gpu_worker.py; gloo transport because the box has one GPU)."""
+    import os
+    r = _torchrun([os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py")], {"PFA_DP_OVERLAP": overlap})
+    assert r.returncode == 0 and "DP_GPU_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_two_ranks_contract():
+    """bench.py under `torch.distributed.run --nproc-per-node 2` (the driver's launch line): both ranks finish, rank 0
+    prints exactly one JSON line with the whole-job rate and the roofline object."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _torchrun([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "128"],
+                  {"PFA_BENCH_BACKEND": "gloo", "PFA_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 0.02 * out["value"]
+    assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out

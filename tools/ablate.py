@@ -1,5 +1,5 @@
 """In-kernel ablation of pfa_gather_gemm on a few BASELINE config-2 layers (developer tool).
-knob 1 bits: 1 no output stores, 2 no stats, 4 no MFMA, 8 no DMA.  knob 0: tile config (1, 4, 5)."""
+knob 1 bits: 1 no output stores, 2 no stats, 4 no MFMA, 8 no DMA.  knob 0: tile (0 auto, 4 = 256x128); knob 2: K-loop (1 reads-first, 2 DMA-first)."""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import torch
@@ -19,12 +19,12 @@ def timeit(f, reps=20):
     return e0.elapsed_time(e1)*1e3/reps
 for name, mode, (h,w,cs), n, (hq,wq), (ho,wo) in L:
     srcs=[T(B,h,w,c) for c in cs]; wgt=T(n,16,sum(cs)); o=torch.empty((B,ho,wo,n),device='cuda',dtype=dt)
-    for cfg in (1, 4, 5):
-        _lib.lib().pfa_set_knob(0, cfg)
+    for cfg in ((0, 1), (0, 2), (0, 3)):
+        _lib.lib().pfa_set_knob(0, cfg[0]); _lib.lib().pfa_set_knob(2, cfg[1])
         row=[]
         for dbg in (0, 1, 4, 8, 12):
             _lib.lib().pfa_set_knob(1, dbg)
             row.append((dbg, timeit(lambda: K.gather_gemm(mode, srcs, wgt, n, [o], (B,hq,wq), ws))))
         _lib.lib().pfa_set_knob(1, 0)
         print(f"{name:9s} cfg{cfg}: " + " ".join(f"[{ {0:'full',1:'nostore',4:'dma-only',8:'mfma-only',12:'skeleton'}[d]}: {t:.1f}]" for d,t in row))
-_lib.lib().pfa_set_knob(0, 0)
+_lib.lib().pfa_set_knob(0, 0); _lib.lib().pfa_set_knob(2, 0)

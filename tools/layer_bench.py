@@ -6,7 +6,9 @@ from pfa_gan import kernels as K, _lib
 B = 16
 dt = torch.bfloat16
 ws = K.Workspace(torch.device('cuda'))
-def T(*shape): return torch.randn(shape, device='cuda', dtype=torch.float32).to(dt)
+import os
+ZERO = os.environ.get('PFA_ZERO') == '1'      # zero operands: the clock the chip holds without data toggling
+def T(*shape): return torch.zeros(shape, device='cuda', dtype=dt) if ZERO else torch.randn(shape, device='cuda', dtype=torch.float32).to(dt)
 # name, mode, src shape (h,w,c parts), n, grid(hq,wq), out hw, taps
 L = [
  ("e2/c2 fwd", K.CONV_S2, (128,128,[64]), 128, (64,64), (64,64)),
@@ -24,7 +26,8 @@ L = [
  ("d2 dgrad",  K.CONV_S2, (128,128,[64]), 256, (64,64), (64,64)),
 ]
 def run(cfg):
-    _lib.lib().pfa_set_knob(0, cfg)
+    tile, loop = cfg
+    _lib.lib().pfa_set_knob(0, tile); _lib.lib().pfa_set_knob(2, loop)
     out = []
     for name, mode, (h,w,cs), n, (hq,wq), (ho,wo) in L:
         srcs = [T(B,h,w,c) for c in cs]
@@ -44,7 +47,8 @@ def run(cfg):
         us = e0.elapsed_time(e1)*1e3/reps
         out.append((name, us, flop/us/1e6))
     return out
-res = {c: run(c) for c in (1, 4, 5)}
+# (tile knob, loop knob): tile 0 auto / 4 = 256x128; loop 1 reads-first / 2 DMA-first / 3 DMA spread over the MFMAs
+res = {c: run(c) for c in ((0, 1), (0, 2), (0, 3), (4, 2))}
 print(f"{'layer':12s} " + "  ".join(f"cfg{c}: us   TF/s" for c in res))
 for i,(name, *_r) in enumerate(L):
     print(f"{name:12s} " + "  ".join(f"{res[c][i][1]:8.1f} {res[c][i][2]:6.0f}" for c in res))
