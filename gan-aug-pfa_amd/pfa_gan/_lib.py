@@ -41,6 +41,15 @@ class WgradArgs(Structure):
     ]
 
 
+class ScatterArgs(Structure):
+    _fields_ = [
+        ("struct_size", c_int32), ("dtype", c_int32), ("nb", c_int32), ("hs", c_int32), ("ws", c_int32),
+        ("c1", c_int32), ("c2", c_int32), ("n", c_int32), ("ld", c_int32), ("act", c_int32), ("slope", c_float),
+        ("reserved", c_int32),
+        ("src1", c_void_p), ("src2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+    ]
+
+
 class ShadowDesc(Structure):
     _fields_ = [("master", c_void_p), ("same", c_void_p), ("tr", c_void_p),
                 ("rows", c_int32), ("c1r", c_int32), ("c1p", c_int32), ("c2r", c_int32), ("c2p", c_int32),
@@ -58,6 +67,8 @@ PROTOTYPES = {
     "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pfa_wgrad": (c_int, [POINTER(WgradArgs), c_void_p]),
+    "pfa_tconv_scatter_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "pfa_tconv_scatter": (c_int, [POINTER(ScatterArgs), c_void_p]),
     "pfa_wgrad_slab_floats": (c_size_t, [POINTER(WgradArgs)]),
     "pfa_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

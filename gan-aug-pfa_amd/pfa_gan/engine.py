@@ -357,8 +357,12 @@ class GeneratorEngine(_Engine):
             ctx.v["uR"][k] = uR
         L = self.up[0]
         fake = ctx.buf("fake", (B, H, W, L.cout_p), dt)
-        K.gather_gemm(K.TCONV_S2, [ctx.v["aR"][0], ctx.v["uR"][1]], L.w_fwd, L.cout, [fake], (B, H // 2, W // 2),
-                      self.ws, bias=L.b, act=K.ACT_TANH)
+        srcs = [ctx.v["aR"][0], ctx.v["uR"][1]]
+        if K.tconv_scatter_ok(srcs, L.cout, fake):        # few output channels: pointwise GEMM + col2im
+            K.tconv_scatter(srcs, L.w_fwd, L.cout, fake, bias=L.b, act=K.ACT_TANH)
+        else:
+            K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [fake], (B, H // 2, W // 2), self.ws, bias=L.b,
+                          act=K.ACT_TANH)
         ctx.v["fake"] = fake
         return fake
 
@@ -528,19 +532,21 @@ class DiscriminatorEngine(_Engine):
             a, h, w = [out], ho, wo
         return a[0]
 
-    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False):
+    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
-        computes and discards D's weight gradients there, train_gan.py:70 then :55)."""
+        computes and discards D's weight gradients there, train_gan.py:70 then :55).
+        need_dx: return dL/d(input) [B,H,W,sum(in_pad)]; with dx_part=i only the gradient of input source i
+        ([B,H,W,in_pad[i]]) is computed - the G phase needs dL/dfake, not dL/dreal_A."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:
-            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side)
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part)
         finally:
             self.ws_cur = self.ws
 
-    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side):
+    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -584,8 +590,16 @@ class DiscriminatorEngine(_Engine):
                     ready = self._finish_fused(Lp, ctx, f"c{i - 1}", rawp, B * hp * wp, garena, dyp, st,
                                                param_grads=param_grads)
                 else:
-                    g = ctx.buf(f"g.c{i}", (B, hin, win, cp), dt)
-                    K.gather_gemm(mode, [dr], L.w_bwd, cp, [g], grid, self.ws_cur)
+                    wb = L.w_bwd
+                    if i == 0 and dx_part is not None:       # rows of w_bwd = input channels: one source's slice
+                        r0 = sum(L.in_pad[:dx_part])
+                        cp = L.in_pad[dx_part]
+                        wb = wb[r0:r0 + cp]
+                    g = ctx.buf(f"g.c{i}" if dx_part is None or i else f"g.c0.{dx_part}", (B, hin, win, cp), dt)
+                    if L.stride == 2 and K.tconv_scatter_ok([dr], cp, g):
+                        K.tconv_scatter([dr], wb, cp, g)
+                    else:
+                        K.gather_gemm(mode, [dr], wb, cp, [g], grid, self.ws_cur)
                     if i == 0:
                         dx = g
         return dx

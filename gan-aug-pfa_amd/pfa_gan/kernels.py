@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, BF16, CONV_S1, CONV_S1_DGRAD, CONV_S2, F32, TCONV_S2,
-                   GatherArgs, WgradArgs, check, lib)
+                   GatherArgs, ScatterArgs, WgradArgs, check, lib)
 
 SLOPE = 0.2          # nn.LeakyReLU(0.2): models.py:178,223,232,240
 BN_EPS = 1e-5        # nn.BatchNorm2d defaults: models.py:179,181,231,239
@@ -146,6 +146,34 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
         a.psum, a.psq = ptr(psum), ptr(psq)
     check(lib().pfa_gather_gemm(ctypes.byref(a), stream()), "pfa_gather_gemm")
     return (psum, psq, a.ntiles_stat) if stats else None
+
+
+SCATTER = _os.environ.get("PFA_SCATTER", "1") != "0"     # PFA_SCATTER=0: always take the implicit-GEMM path (A/B runs)
+
+
+def tconv_scatter_ok(srcs, n, out):
+    """True when tconv_scatter() can replace gather_gemm(TCONV_S2, ...) for these operands."""
+    if not SCATTER or len(srcs) > 2:
+        return False
+    c2 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    return bool(lib().pfa_tconv_scatter_supported(dt_code(srcs[0].dtype), srcs[0].shape[3], c2, n, out.shape[3]))
+
+
+def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE):
+    """out = act(bias + ConvTranspose2d_{k4,s2,p1}([srcs]))) for n <= 8 output channels: pointwise MFMA GEMM per input
+    patch + col2im in LDS (csrc/tconv_scatter.hip).  Same operands and result as gather_gemm(TCONV_S2, ...)."""
+    _require_cuda(*srcs, w, out)
+    a = ScatterArgs()
+    a.struct_size = ctypes.sizeof(ScatterArgs)
+    a.dtype = dt_code(srcs[0].dtype)
+    a.nb, a.hs, a.ws = srcs[0].shape[:3]
+    a.c1 = srcs[0].shape[3]
+    a.c2 = srcs[1].shape[3] if len(srcs) > 1 else 0
+    a.n, a.ld = n, out.shape[3]
+    a.act, a.slope = act, SLOPE
+    a.src1, a.src2 = ptr(srcs[0]), ptr(srcs[1]) if len(srcs) > 1 else None
+    a.w, a.bias, a.out = ptr(w), ptr(bias), ptr(out)
+    check(lib().pfa_tconv_scatter(ctypes.byref(a), stream()), "pfa_tconv_scatter")
 
 
 FORCE_SLAB = object()     # pass as ws= to force the slab combine whatever the slice count (tests)

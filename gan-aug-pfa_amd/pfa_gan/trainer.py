@@ -180,9 +180,9 @@ class GanTrainer:
         lg = Dn.forward([xa, fake], self.ctx_r, train=True)
         dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
         K.bce_logits(lg, 1.0, 1.0, 1.0, self.losses[1:2], dl_g)
-        dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True)
+        dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
-        K.l1_tanh_bwd(fake, xb, G.out_nc, dx, xa.shape[3], self.lambda_l1, self.losses[1:2], dpre)
+        K.l1_tanh_bwd(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self.losses[1:2], dpre)
         garena = self.opt_g.flat().grad
         self._works = []
         hook = None

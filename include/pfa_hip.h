@@ -136,6 +136,36 @@ typedef struct pfa_wgrad_args {
 size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a);
 int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s);
 
+/* ------------------------------------------------------------------ transposed conv onto <= 8 channels
+ * out[b][2*iy-1+ky][2*ix-1+kx][co] = act( bias[co] + sum_c src[b][iy][ix][c] * w[co][ky*4+kx][c] )
+ * Replaces, where the output has only a few channels: the generator's outermost
+ * ConvTranspose2d(2*ngf, 3, 4, 2, 1) + Tanh (models.py:184-186) and the input gradient of the
+ * discriminator's first Conv2d(6, ndf, 4, 2, 1) (models.py:223, needed by train_gan.py:66-70).
+ * Same result as pfa_gather_gemm(PFA_TCONV_S2) with the same operands; the input is staged once
+ * per patch (pointwise MFMA GEMM + col2im in LDS) instead of once per tap and parity class.
+ * src1|src2: NHWC [nb][hs][ws][c1|c2] virtual concat, c1 and c2 multiples of one 128-byte chunk
+ * (64 bf16 / 32 f32 channels; c2 may be 0); w: [n][16][c1+c2] (rows >= n are never read);
+ * out: NHWC [nb][2hs][2ws][ld], lanes [n, ld) written as zeros.  pfa_tconv_scatter_supported
+ * returns 1 when these constraints hold (callers fall back to pfa_gather_gemm otherwise).
+ */
+typedef struct pfa_scatter_args {
+    int32_t struct_size;
+    int32_t dtype;
+    int32_t nb, hs, ws;
+    int32_t c1, c2;
+    int32_t n, ld;
+    int32_t act;
+    float slope;
+    int32_t reserved;
+    const void* src1;
+    const void* src2;
+    const void* w;
+    const float* bias;           /* [n] or NULL */
+    void* out;
+} pfa_scatter_args;
+int pfa_tconv_scatter_supported(int dtype, int c1, int c2, int n, int ld);
+int pfa_tconv_scatter(const pfa_scatter_args* a, pfa_stream s);
+
 /* ------------------------------------------------------------------ BatchNorm2d (training)
  * Replaces nn.BatchNorm2d (models.py:179,181,231,239): eps 1e-5, momentum 0.1, biased batch
  * variance for normalisation, unbiased for running_var.  Statistics arrive as per-tile

@@ -141,6 +141,61 @@ def test_convT_forward(case, dtype, ws):
           scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
 
 
+SCATTER_CASES = [  # name, N, cin parts, H, W, Co, bias, act
+    ("d1", 2, [64, 64], 8, 8, 3, True, K.ACT_TANH),              # the generator's output layer: two 64-channel sources
+    ("d1_ragged", 1, [64, 64], 7, 33, 3, True, K.ACT_TANH),      # H not a multiple of the 6-row tile, W crosses a tile
+    ("one_tile", 2, [64], 6, 30, 3, False, K.ACT_NONE),          # exactly one interior tile, single source
+    ("c1_dgrad_like", 2, [64], 13, 31, 6, False, K.ACT_NONE),    # 6 real of 8 columns per tap
+    ("n8_relu", 1, [128], 5, 61, 8, True, K.ACT_RELU),
+    ("n1", 1, [64], 3, 4, 1, True, K.ACT_NONE),
+    ("1x1", 3, [64], 1, 1, 3, True, K.ACT_TANH),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", SCATTER_CASES, ids=[c[0] for c in SCATTER_CASES])
+def test_tconv_scatter(case, dtype, ws):
+    """pfa_tconv_scatter (pointwise GEMM + col2im) against the oracle's ConvTranspose2d, and against the implicit-GEMM
+    path on the same operands."""
+    name, n, cins, h, w, co, bias, act = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".sx", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".sw", (ci, co, 4, 4), -0.25, 0.25), dtype)
+    b = fill.uniform(name + ".sb", (co,), -0.5, 0.5) if bias else None
+    raw = ops.convT2d_fwd(x, wt, b)
+    want = np.tanh(raw) if act == K.ACT_TANH else np.maximum(raw, 0) if act == K.ACT_RELU else raw
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    _, tr = shadows(wt, dtype, want=("tr",))
+    cp = K.pad_ch(co, dtype)
+    out = torch.full((n, 2 * h, 2 * w, cp), 7.0, dtype=dtype, device="cuda")
+    bt = torch.from_numpy(b).cuda() if bias else None
+    assert K.tconv_scatter_ok(srcs, co, out)
+    K.tconv_scatter(srcs, tr, co, out, bias=bt, act=act)
+    close(from_nhwc(out, co), want, dtype, name)
+    torch.cuda.synchronize()
+    assert float(out[..., co:].float().abs().max()) == 0.0 if cp > co else True, "pad lanes must be exact zeros"
+    ref = torch.full_like(out, 7.0)
+    K.gather_gemm(K.TCONV_S2, srcs, tr, co, [ref], (n, h, w), ws, bias=bt, act=act)
+    close(from_nhwc(out, co), from_nhwc(ref, co), dtype, name + " vs implicit GEMM")
+
+
+def test_tconv_scatter_support_and_errors():
+    bf = torch.bfloat16
+    x16 = torch.zeros((1, 4, 4, 16), dtype=bf, device="cuda")
+    x64 = torch.zeros((1, 4, 4, 64), dtype=bf, device="cuda")
+    out8 = torch.zeros((1, 8, 8, 8), dtype=bf, device="cuda")
+    out16 = torch.zeros((1, 8, 8, 16), dtype=bf, device="cuda")
+    assert not K.tconv_scatter_ok([x16], 3, out8)          # channel count is not a whole 128-byte chunk
+    assert not K.tconv_scatter_ok([x64], 12, out16)        # more than 8 output channels
+    assert K.tconv_scatter_ok([x64], 3, out8)
+    w = torch.zeros((8, 16, 16), dtype=bf, device="cuda")
+    with pytest.raises(_lib.PfaError, match="128-byte chunk"):
+        K.tconv_scatter([x16], w, 3, out8)
+
+
 # ---------------------------------------------------------------------------- input gradients
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize("case", [("s2", 2, 16, 8, 8, 32, 2), ("s2_c1like", 2, 6, 16, 16, 64, 2),
