@@ -502,6 +502,22 @@ __global__ __launch_bounds__(256) void k_unpack_nchw(const T* __restrict__ src, 
     }
 }
 
+// NHWC (padded) -> packed HWC uint8 image rows, u8 = byte((x*mul + add) * 255): the reference's `tensor*0.5+0.5` followed
+// by TF.to_pil_image's mul(255).byte() (generate_synthetic_data.py:66-71), each product / sum rounded on its own like the
+// separate torch kernels (no fused multiply-add), the final conversion truncating.
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_u8(const T* __restrict__ src, int64_t pixels, int c, int cp, float mul,
+                                                   float add, uint8_t* __restrict__ dst) {
+    const int64_t total = pixels * c;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pix = idx / c;
+        const int ch = (int)(idx - pix * c);
+        const float t = __fadd_rn(__fmul_rn(to_f32(src[pix * cp + ch]), mul), add);
+        const float v = __fmul_rn(t, 255.f);
+        dst[idx] = (uint8_t)(int)fminf(fmaxf(v, 0.f), 255.f);
+    }
+}
+
 }  // namespace
 
 #define DISPATCH_T(dtype, expr_bf16, expr_f32)           \
@@ -755,6 +771,18 @@ extern "C" int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int 
                hipLaunchKernelGGL(k_unpack_nchw<float>, dim3(grid_for(n * c * hw)), dim3(256), 0, (hipStream_t)s,
                                   (const float*)src, n, c, hw, cp, dst));
     PFA_LAUNCHED("k_unpack_nchw");
+    return 0;
+}
+
+extern "C" int pfa_unpack_u8(const void* src, int64_t pixels, int c, int cp, int dtype, float mul, float add,
+                             uint8_t* dst, pfa_stream s) {
+    PFA_REQUIRE(src && dst && pixels > 0 && c > 0 && cp >= c, "pfa_unpack_u8: bad arguments");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_unpack_u8<bf16_t>, dim3(grid_for(pixels * c)), dim3(256), 0, (hipStream_t)s,
+                                  (const bf16_t*)src, pixels, c, cp, mul, add, dst),
+               hipLaunchKernelGGL(k_unpack_u8<float>, dim3(grid_for(pixels * c)), dim3(256), 0, (hipStream_t)s,
+                                  (const float*)src, pixels, c, cp, mul, add, dst));
+    PFA_LAUNCHED("k_unpack_u8");
     return 0;
 }
 

@@ -53,7 +53,7 @@ def generate_data(args):
         if batch is None:
             continue
         a = batch["image1"].to(device)
-        fake = gen(a)
+        fake_u8 = gen.generate_uint8(a).cpu().numpy()       # [B,H,W,3] bytes: de-normalised and converted on the device
         for j in range(a.size(0)):
             idx = i * args.batch_size + j
             city = batch["city"][j]
@@ -62,7 +62,7 @@ def generate_data(args):
             os.makedirs(img_dir, exist_ok=True)
             os.makedirs(lbl_dir, exist_ok=True)
             Image.fromarray(to_uint8_image(a[j] * 0.5 + 0.5)).save(os.path.join(img_dir, f"img1_synth_{idx}.png"))
-            Image.fromarray(to_uint8_image(fake[j] * 0.5 + 0.5)).save(os.path.join(img_dir, f"img2_synth_{idx}.png"))
+            Image.fromarray(fake_u8[j]).save(os.path.join(img_dir, f"img2_synth_{idx}.png"))
             Image.fromarray((batch["label"][j].byte() * 255).numpy()).save(os.path.join(lbl_dir, f"cm_synth_{idx}.png"))
             count += 1
     print(f"\nSynthetic data generation finished. Saved {count} samples to {args.out_dir}")

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "pfa_weight_shadow_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pfa_pack_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_unpack_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pfa_unpack_u8": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pfa_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
 }
 

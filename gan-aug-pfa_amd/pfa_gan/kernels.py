@@ -321,5 +321,17 @@ def unpack_nchw(x, c, out=None):
     return out
 
 
+def unpack_u8(x, c, mul=0.5, add=0.5, out=None):
+    """NHWC (padded) -> uint8 [N,H,W,c] = byte((x*mul + add) * 255): the PNG bytes of generate_synthetic_data.py:66-71
+    (`t*0.5+0.5` then TF.to_pil_image), produced on the device so one byte per sample crosses PCIe."""
+    _require_cuda(x)
+    n, h, w, cp = x.shape
+    if out is None:
+        out = torch.empty((n, h, w, c), dtype=torch.uint8, device=x.device)
+    check(lib().pfa_unpack_u8(ptr(x), n * h * w, c, cp, dt_code(x.dtype), float(mul), float(add), ptr(out), stream()),
+          "pfa_unpack_u8")
+    return out
+
+
 def fill_zero(t):
     check(lib().pfa_fill_zero(ptr(t), t.numel() * t.element_size(), stream()), "pfa_fill_zero")

@@ -145,6 +145,19 @@ class UNetGenerator(nn.Module):
         from .autograd import generator_apply
         return generator_apply(self, input)
 
+    @torch.no_grad()
+    def generate_uint8(self, input):
+        """Inference fast path of generate_synthetic_data.py:61-71: G(input) de-normalised (x*0.5+0.5) and converted to
+        PNG bytes the way TF.to_pil_image does (mul(255).byte()).  NCHW float batch in [-1,1] -> uint8 [B,H,W,C]; on a
+        GPU input the conversion runs on the device (libpfa_hip), on a CPU input it is the same arithmetic in torch."""
+        if not input.is_cuda:
+            return (self.model(input) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).contiguous()
+        from . import kernels as K
+        eng = self.engine()
+        eng.refresh_shadows(force=True)
+        fake = eng.forward(K.pack_nhwc(input, eng.dtype), eng.scratch_ctx(), train=self.training, bn_repeats=1)
+        return K.unpack_u8(fake, eng.out_nc, 0.5, 0.5)
+
 
 class NLayerDiscriminator(nn.Module):
     """PatchGAN discriminator.  NLayerDiscriminator(input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d)."""

@@ -241,6 +241,10 @@ int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int same_bl
 /* NCHW float32 [n][c][h][w] <-> NHWC `dtype` [n][h][w][cp] (cp >= c, pad lanes zero / ignored). */
 int pfa_pack_nhwc(const float* src, int n, int c, int h, int w, int cp, int dtype, void* dst, pfa_stream s);
 int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dtype, float* dst, pfa_stream s);
+/* Inference output (generate_synthetic_data.py:66-71): NHWC [pixels][cp] -> packed uint8 [pixels][c],
+ * u8 = byte((x*mul + add) * 255) with torch's rounding order (x*0.5+0.5, then TF.to_pil_image's mul(255).byte()). */
+int pfa_unpack_u8(const void* src, int64_t pixels, int c, int cp, int dtype, float mul, float add, uint8_t* dst,
+                  pfa_stream s);
 int pfa_fill_zero(void* p, size_t bytes, pfa_stream s);
 
 #ifdef __cplusplus

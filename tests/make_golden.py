@@ -372,14 +372,54 @@ def gen_step(models, train_gan):
     print("step.npz", len(s), "arrays")
 
 
+def gen_siamese(models):
+    """SiameseUNet (models.py:47-145): state_dict keys in order, a digest of the seeded default init, and the train /
+    eval forward on filler weights.  The module is outside the accelerated path; the fixture pins the drop-in's
+    plain-torch restatement (gan-aug-pfa_amd/pfa_gan/siamese.py)."""
+    s = {}
+    torch.manual_seed(7)
+    ref = models.SiameseUNet(3, 2)
+    st0 = ref.state_dict()
+    s["siamese.keys"] = np.array("\n".join(st0.keys()))
+    s["siamese.init_sums"] = np.array([float(v.double().sum()) for v in st0.values()], np.float64)
+    shapes = {k: tuple(v.shape) for k, v in st0.items()}
+    st = fill.fill_state(shapes, seed=3)
+    for k in shapes:                                  # non-trivial running statistics for the eval pass
+        if k.endswith("running_mean"):
+            st[k] = fill.uniform(k, shapes[k], -0.2, 0.2, 3)
+        elif k.endswith("running_var"):
+            st[k] = fill.uniform(k, shapes[k], 0.5, 1.5, 3)
+    load_state(ref, st)
+    x1, x2 = t(fill.uniform("siamese.x1", (2, 3, 32, 32))), t(fill.uniform("siamese.x2", (2, 3, 32, 32)))
+    ref.eval()
+    with torch.no_grad():
+        s["siamese.out_eval"] = ref(x1, x2).numpy()
+    ref.train()
+    out = ref(x1, x2)
+    s["siamese.out_train"] = out.detach().numpy()
+    out.square().mean().backward()
+    s["siamese.grad_conv_last"] = ref.conv_last.weight.grad.numpy().copy()
+    s["siamese.grad_down1"] = ref.dconv_down1[0].weight.grad.numpy().copy()
+    s["siamese.rm_after_train"] = ref.state_dict()["bottleneck.1.running_mean"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "siamese.npz"), **s)
+    print("siamese.npz", len(s), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     models, train_gan = import_reference()
-    gen_ops()
-    gen_nets(models)
-    gen_full(models)
-    gen_step(models, train_gan)
+    which = sys.argv[1:] or ["ops", "nets", "full", "step", "siamese"]      # e.g. `make_golden.py siamese` redoes one file
+    if "ops" in which:
+        gen_ops()
+    if "nets" in which:
+        gen_nets(models)
+    if "full" in which:
+        gen_full(models)
+    if "step" in which:
+        gen_step(models, train_gan)
+    if "siamese" in which:
+        gen_siamese(models)
     with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
         f.write("generated by tests/make_golden.py from /root/reference (Affi-Amine/GAN-AUG-PFA @ 2025-06-14)\n")
         f.write(f"torch {torch.__version__} CPU, numpy {np.__version__}\n")

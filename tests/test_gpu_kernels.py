@@ -407,3 +407,18 @@ def test_argument_errors_are_reported():
         _lib.check(_lib.lib().pfa_gather_gemm(a, None), "pfa_gather_gemm")
     with pytest.raises(_lib.PfaError, match="GPU tensors"):
         K.pack_nhwc(torch.zeros(1, 3, 4, 4), torch.float32)
+
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+def test_unpack_u8_matches_to_pil_image_arithmetic(dtype):
+    """pfa_unpack_u8 against `(t*0.5+0.5).mul(255).byte()` (generate_synthetic_data.py:66-71 + TF.to_pil_image), bit
+    for bit, including the ends of the Tanh range."""
+    x = fill.uniform("u8.x", (2, 3, 9, 7))
+    x[0, :, 0, 0] = [-1.0, 1.0, 0.0]
+    x[0, :, 0, 1] = [0.99999994, -0.99999994, 0.5]
+    x = rnd(x, dtype)
+    t = to_nhwc(x, dtype)
+    got = K.unpack_u8(t, 3).cpu().numpy()
+    want = (torch.from_numpy(x) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)

@@ -368,3 +368,17 @@ def test_bench_two_ranks_contract():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 0.02 * out["value"]
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_generate_uint8_equals_denormalised_forward(precision):
+    """generate_synthetic_data.py:61-71 on the device: the uint8 image equals (G(x)*0.5+0.5).mul(255).byte() of the same
+    eval-mode forward, byte for byte."""
+    torch.manual_seed(3)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda().set_precision(precision).eval()
+    x = torch.rand((2, 3, 64, 32), device="cuda") * 2 - 1
+    with torch.no_grad():
+        want = (G(x) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).cpu()
+    got = G.generate_uint8(x).cpu()
+    assert got.dtype == torch.uint8 and got.shape == (2, 64, 32, 3)
+    assert torch.equal(got, want)

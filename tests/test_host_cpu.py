@@ -161,3 +161,42 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     # per-replica BN statistics: rank 0 saw rank 0's shard only -> its running buffers equal the single-rank ones
     # after the first forward would differ only through the weights; counters are exact
     assert [int(b) for b in r["bn"] if b.dtype == torch.int64] == [int(b) for b in G.buffers() if b.dtype == torch.int64]
+
+
+def test_siamese_unet_dropin_matches_reference_golden(golden):
+    """`from models import SiameseUNet` (reference train.py:16, evaluate.py:12) resolves to a plain-torch module with the
+    reference's state_dict keys (in order), seeded default init and train / eval arithmetic (tests/golden/siamese.npz,
+    generated from the reference by tests/make_golden.py)."""
+    sys.path.insert(0, PKG)
+    try:
+        import models as dropin
+    finally:
+        sys.path.remove(PKG)
+    z = golden("siamese")
+    torch.manual_seed(7)
+    net = dropin.SiameseUNet(3, 2)
+    st0 = net.state_dict()
+    assert list(st0.keys()) == str(z["siamese.keys"]).split("\n")
+    sums = np.array([float(v.double().sum()) for v in st0.values()])
+    np.testing.assert_allclose(sums, z["siamese.init_sums"], rtol=0, atol=0)       # same RNG consumption order
+    shapes = {k: tuple(v.shape) for k, v in st0.items()}
+    st = fill.fill_state(shapes, seed=3)
+    for k in shapes:
+        if k.endswith("running_mean"):
+            st[k] = fill.uniform(k, shapes[k], -0.2, 0.2, 3)
+        elif k.endswith("running_var"):
+            st[k] = fill.uniform(k, shapes[k], 0.5, 1.5, 3)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in st.items()}, strict=True)
+    x1 = torch.from_numpy(fill.uniform("siamese.x1", (2, 3, 32, 32)))
+    x2 = torch.from_numpy(fill.uniform("siamese.x2", (2, 3, 32, 32)))
+    net.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(net(x1, x2).numpy(), z["siamese.out_eval"], rtol=1e-5, atol=1e-5)
+    net.train()
+    out = net(x1, x2)
+    np.testing.assert_allclose(out.detach().numpy(), z["siamese.out_train"], rtol=1e-5, atol=1e-5)
+    out.square().mean().backward()
+    np.testing.assert_allclose(net.conv_last.weight.grad.numpy(), z["siamese.grad_conv_last"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(net.dconv_down1[0].weight.grad.numpy(), z["siamese.grad_down1"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(net.state_dict()["bottleneck.1.running_mean"].numpy(), z["siamese.rm_after_train"],
+                               rtol=1e-5, atol=1e-6)
