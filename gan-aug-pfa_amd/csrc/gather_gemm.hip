@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     }
 
     float fs[FN][4], fq[FN][4];        // per-lane partial statistics (filled by the fused backward, else from acc)
-    if (p.fuse_out) {
+    if (p.fuse_out == 1 || p.fuse_out == 2) {
         // This launch computes g = dL/d(act(y)) for the tensor `raw` (y = scale*raw + shift).  Turn it into
         // dy = act1'(y)*g (+ act2'(y)*g2) right here and collect the BatchNorm-backward sums (dy, dy*xhat) per column:
         // the separate elementwise pass over g, raw and dy disappears.
@@ -542,6 +542,22 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         }
     }
 
+    if (p.fuse_out == 3) {
+        // Eval-mode BatchNorm folded into the epilogue: y = scale[n]*acc + shift[n] (coefficients from the running
+        // statistics, known before the launch); out1 = act(y) and, when given, out2 = fuse_act2(y) over the same columns.
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool nv = nbase + r < p.n;
+                const float sc = nv ? p.fuse_scale[nbase + r] : 0.f, sh = nv ? p.fuse_shift[nbase + r] : 0.f;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) acc[a][b][r] = mval[b] ? acc[a][b][r] * sc + sh : 0.f;
+            }
+        }
+    }
+
     if (p.psum && !(p.dbg & 2)) {
         // per-column sums over this tile's rows (rows >= M are exact zeros: their operands were the zero page,
         // and BatchNorm layers carry no bias)
@@ -552,7 +568,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float s = 0.f, q = 0.f;
-                if (p.fuse_out) { s = fs[a][r]; q = fq[a][r]; }
+                if (p.fuse_out == 1 || p.fuse_out == 2) { s = fs[a][r]; q = fq[a][r]; }
                 else {
 #pragma unroll
                     for (int b = 0; b < FM; ++b) { const float v = acc[a][b][r]; s += v; q += v * v; }
@@ -583,6 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
         char* obase; int col, ld;
         if (nbase < p.n1) { obase = p.out1; col = nbase; ld = p.ld1; }
+        else if (p.fuse_out == 3) continue;          // affine mode: out2 mirrors out1's columns, nothing lives beyond n1
         else { obase = p.out2; col = nbase - p.n1; ld = p.ld2; }
         if (col < ld && !(p.dbg & 1)) {
 #pragma unroll
@@ -598,6 +615,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                     else v[r] = t;
                 }
                 store4<T>(obase + (opix[b] * ld + col) * sizeof(T), v);
+                if (p.fuse_out == 3 && p.out2 && col < p.ld2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[a][b][r], p.fuse_act2, p.slope);
+                    store4<T>(p.out2 + (opix[b] * p.ld2 + col) * sizeof(T), v);
+                }
             }
         }
     }
@@ -762,7 +784,13 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.fuse_raw = (const char*)a->fuse_raw; k.fuse_g2 = (const char*)a->fuse_g2;
     k.fuse_scale = a->fuse_scale; k.fuse_shift = a->fuse_shift; k.fuse_mean = a->fuse_mean; k.fuse_invstd = a->fuse_invstd;
     k.stat_col0 = 0; k.stat_n = a->n;
-    if (a->fuse_out) {
+    if (a->fuse_out == 3) {
+        PFA_REQUIRE(a->fuse_scale && a->fuse_shift, "pfa_gather_gemm: the affine epilogue needs scale and shift");
+        PFA_REQUIRE(a->n1 >= a->n && a->bias == nullptr && a->psum == nullptr && a->act != PFA_ACT_TANH &&
+                    a->fuse_act2 != PFA_ACT_TANH,
+                    "pfa_gather_gemm: the affine epilogue writes all columns to out1 (n1 >= n), without bias, statistics or tanh");
+        PFA_REQUIRE(a->out2 == nullptr || a->ld2 == a->ld1, "pfa_gather_gemm: affine epilogue outputs must share one row length");
+    } else if (a->fuse_out) {
         PFA_REQUIRE(a->fuse_out == 1 || (a->fuse_out == 2 && a->ld2 > 0), "pfa_gather_gemm: fuse_out must name an existing output");
         PFA_REQUIRE(a->fuse_raw && (a->fuse_scale == nullptr) == (a->fuse_shift == nullptr) &&
                     (a->fuse_mean == nullptr) == (a->fuse_invstd == nullptr), "pfa_gather_gemm: incomplete fused-backward arguments");
@@ -773,7 +801,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of splitk*pixels*round4(n) floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
-    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1), "pfa_gather_gemm: the fused backward epilogue cannot be combined with split-K");
+    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1), "pfa_gather_gemm: a fused epilogue (fuse_out) cannot be combined with split-K");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
     if (a->mode == PFA_CONV_S1) PFA_REQUIRE(a->hs == a->hq + 1 && a->ws == a->wq + 1, "pfa_gather_gemm: CONV_S1 needs hs=hq+1");
@@ -897,7 +925,7 @@ extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int
 extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
-    PFA_REQUIRE(!a->fuse_out || (a->fuse_mean != nullptr) == (a->psum != nullptr),
+    PFA_REQUIRE(!(a->fuse_out == 1 || a->fuse_out == 2) || (a->fuse_mean != nullptr) == (a->psum != nullptr),
                 "pfa_gather_gemm: a fused BatchNorm backward needs psum/psq, a fused activation backward must not pass them");
     hipStream_t st = (hipStream_t)s;
     const TileCfg cfg = choose_cfg(k);

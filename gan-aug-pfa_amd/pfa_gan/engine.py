@@ -14,6 +14,8 @@ Activations are NHWC, bf16 or f32, channel-padded to 16 bytes.  Parameters live 
 float32 arena per network (every nn.Parameter is a view into it, conv weights in channels-last
 memory = the kernels' [rows][16][c] layout); gradients accumulate into a matching arena.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -231,6 +233,23 @@ class _Engine:
             self._versions = versions
 
     # BatchNorm plumbing ------------------------------------------------------------
+    @staticmethod
+    def _affine_ok(mode, srcs, n, grid):
+        """The affine epilogue needs an un-split launch (split-K results are combined by the finish kernel)."""
+        if os.environ.get("PFA_AFFINE", "1") == "0":       # A/B switch
+            return False
+        return K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(t.shape[3] for t in srcs), srcs[0].dtype) == 1
+
+    def _eval_affine(self, L, ctx, tag):
+        """(scale, shift) of the layer's eval-mode normalisation; the identity for a layer without a norm."""
+        if L.bn is None:
+            one = ctx.buf(tag + ".one", (L.cout,), torch.float32)
+            zero = ctx.buf(tag + ".zero", (L.cout,), torch.float32)
+            one.fill_(1.0)
+            zero.zero_()
+            return one, zero
+        return self._bn_coeffs(L, ctx, tag, None, 1, False, 1)
+
     def _bn_coeffs(self, L, ctx, tag, st, count, train, repeats):
         c = L.cout
         f32 = torch.float32
@@ -334,8 +353,16 @@ class GeneratorEngine(_Engine):
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aR], (B, h, w), self.ws, act=K.ACT_RELU)
                 ctx.v["aR"][k] = aR
                 break
-            raw = ctx.buf(f"e{k}.raw", shape, dt)
             aL, aR = ctx.buf(f"e{k}.aL", shape, dt), ctx.buf(f"e{k}.aR", shape, dt)
+            if not train and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w)):
+                # eval: the normalisation is a per-channel affine map known up front - apply it in the GEMM epilogue
+                # and emit both readers' operands from there (no raw tensor, no separate pass)
+                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aL, aR], (B, h, w), self.ws, act=K.ACT_LRELU,
+                              affine=self._eval_affine(L, ctx, f"e{k}") + (K.ACT_RELU,))
+                ctx.v["aL"][k], ctx.v["aR"][k] = aL, aR
+                a = aL
+                continue
+            raw = ctx.buf(f"e{k}.raw", shape, dt)
             if L.bn is None:        # outermost: no norm
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws)
                 K.bn_act(raw, None, None, aL, aR)
@@ -349,6 +376,12 @@ class GeneratorEngine(_Engine):
             L = self.up[k]
             h, w = H >> (k + 1), W >> (k + 1)
             srcs = [ctx.v["aR"][k]] if k == D - 1 else [ctx.v["aR"][k], ctx.v["uR"][k + 1]]
+            if not train and self._affine_ok(K.TCONV_S2, srcs, L.cout, (B, h, w)):
+                uR = ctx.buf(f"u{k}.uR", (B, 2 * h, 2 * w, L.cout_p), dt)
+                K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [uR], (B, h, w), self.ws, act=K.ACT_RELU,
+                              affine=self._eval_affine(L, ctx, f"u{k}") + (K.ACT_NONE,))
+                ctx.v["uR"][k] = uR
+                continue
             raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
             st = K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
             scale, shift = self._bn_coeffs(L, ctx, f"u{k}", st, B * 4 * h * w, train, bn_repeats)

@@ -92,13 +92,16 @@ def auto_splitk(mode, srcs, n, grid):
     return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(s.shape[3] for s in srcs), srcs[0].dtype)
 
 
-def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None):
+def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None,
+                affine=None):
     """out = act(bias + implicit_gemm(srcs, w)).  srcs/outs: lists of 1 or 2 NHWC tensors.
 
     grid = (nb, hq, wq) position grid.  Returns (psum, psq, ntiles) views when stats=True.
     fuse: dict(out=1|2, raw=, act1=, g2=None, act2=, scale=, shift=, mean=, invstd=) - the named output receives
     dy = act1'(y)*g + act2'(y)*g2 (activation / BatchNorm backward fused into this input-gradient launch); with
     mean/invstd the call returns (part, None, ntiles) for bn_bwd_finalize.
+    affine: (scale, shift, act2) - eval-mode BatchNorm in the epilogue: outs[0] = act(scale*acc + shift) and, with two
+    outs, outs[1] = act2(scale*acc + shift) over the same columns (needs splitk == 1: check auto_splitk first).
     """
     _require_cuda(*srcs, w, *outs)
     dtype = srcs[0].dtype
@@ -123,6 +126,9 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     if a.splitk > 1:
         a.slab = ptr(ws.get("slab", a.splitk * npix * ((n + 3) // 4 * 4)))
     psum = psq = None
+    if affine is not None:
+        a.fuse_out, a.fuse_act2 = 3, affine[2]
+        a.fuse_scale, a.fuse_shift = ptr(affine[0]), ptr(affine[1])
     if fuse is not None:
         a.fuse_out, a.fuse_act1, a.fuse_act2 = fuse["out"], fuse["act1"], fuse.get("act2", ACT_NONE)
         a.fuse_raw, a.fuse_g2 = ptr(fuse["raw"]), ptr(fuse.get("g2"))

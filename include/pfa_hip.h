@@ -85,11 +85,14 @@ typedef struct pfa_gather_args {
     float* psum;                 /* optional BatchNorm partial sums   [tiles][n]    */
     float* psq;                  /* optional partial sums of squares  [tiles][n]    */
     float* slab;                 /* splitk>1: float32 [splitk][pixels][round4(n)] workspace */
+    /* fuse_out == 3, eval-mode BatchNorm folded into a forward launch (generate_synthetic_data.py:55, splitk == 1, no
+     * bias, n1 >= n): y = fuse_scale[n]*acc + fuse_shift[n]; out1 = act(y); out2, if not NULL, = fuse_act2(y) over the
+     * same columns (the LeakyReLU and ReLU readers of one encoder activation, models.py:204-208). */
     /* Fused activation / BatchNorm backward (input-gradient launches, splitk == 1, no bias/act): the chosen output
      * receives dy = act1'(y)*g + act2'(y)*g2 instead of g, with y = scale*raw + shift (scale NULL: y = raw) and raw the
      * conv output that output is the gradient of (same shape).  With mean/invstd, psum/psq receive the per-tile
      * sums of dy and dy*xhat over the fused output's columns (row length = its ld) for pfa_bn_bwd_finalize. */
-    int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2                                  */
+    int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2, 3 = affine epilogue (below)      */
     int32_t fuse_act1, fuse_act2;
     int32_t reserved;
     const void* fuse_raw;

@@ -141,6 +141,54 @@ def test_convT_forward(case, dtype, ws):
           scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
 
 
+AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs
+    ("enc_small", "conv", 2, [8], 16, 16, 8, True),             # narrow staging, 256x16 tile
+    ("enc_mid", "conv", 2, [64], 32, 32, 96, True),             # 128x128 tile, ragged columns
+    ("enc_e1", "conv", 2, [3], 32, 32, 64, True),               # 3-channel image layer, 128x64 tile
+    ("dec", "tconv", 2, [64, 64], 8, 8, 48, False),             # transposed conv, virtual concat, one output
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", AFFINE_CASES, ids=[c[0] for c in AFFINE_CASES])
+def test_affine_epilogue(case, dtype, ws):
+    """fuse_out = 3: out1 = LeakyReLU/ReLU(scale*conv + shift), out2 = ReLU(scale*conv + shift) - the eval-mode
+    BatchNorm of generate_synthetic_data.py:55 applied inside the launch."""
+    name, mode, n, cins, h, w, co, dual = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".ax", (n, ci, h, w)), dtype)
+    scale = fill.uniform(name + ".asc", (co,), 0.5, 1.5)
+    shift = fill.uniform(name + ".ash", (co,), -0.5, 0.5)
+    parts, srcs, o = [], [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        parts.append((c, K.pad_ch(c, dtype)))
+        o += c
+    if mode == "conv":
+        wt = rnd(fill.uniform(name + ".aw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        raw = ops.conv2d_fwd(x, wt, None, 2)
+        wdev, _ = shadows(wt, dtype, cparts=parts, want=("same",))
+        gmode, grid = K.CONV_S2, (n, h // 2, w // 2)
+    else:
+        wt = rnd(fill.uniform(name + ".aw", (ci, co, 4, 4), -0.25, 0.25), dtype)
+        raw = ops.convT2d_fwd(x, wt, None)
+        _, wdev = shadows(wt, dtype, want=("tr",))
+        gmode, grid = K.TCONV_S2, (n, h, w)
+    y = raw * scale[None, :, None, None] + shift[None, :, None, None]
+    ho, wo = raw.shape[2:]
+    cp = K.pad_ch(co, dtype)
+    outs = [torch.full((n, ho, wo, cp), 7.0, dtype=dtype, device="cuda") for _ in range(2 if dual else 1)]
+    sc, sh = torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda()
+    act1 = K.ACT_LRELU if dual else K.ACT_RELU
+    K.gather_gemm(gmode, srcs, wdev, co, outs, grid, ws, act=act1, splitk=1, affine=(sc, sh, K.ACT_RELU))
+    close(from_nhwc(outs[0], co), ops.leaky_relu(y) if dual else ops.relu(y), dtype, name + " out1", scale=np.abs(y).max())
+    if dual:
+        close(from_nhwc(outs[1], co), ops.relu(y), dtype, name + " out2", scale=np.abs(y).max())
+    for t in outs:
+        if cp > co:
+            assert float(t[..., co:].float().abs().max()) == 0.0, "pad channels must be written as zeros"
+
+
 SCATTER_CASES = [  # name, N, cin parts, H, W, Co, bias, act
     ("d1", 2, [64, 64], 8, 8, 3, True, K.ACT_TANH),              # the generator's output layer: two 64-channel sources
     ("d1_ragged", 1, [64, 64], 7, 33, 3, True, K.ACT_TANH),      # H not a multiple of the 6-row tile, W crosses a tile

@@ -382,3 +382,38 @@ def test_generate_uint8_equals_denormalised_forward(precision):
     got = G.generate_uint8(x).cpu()
     assert got.dtype == torch.uint8 and got.shape == (2, 64, 32, 3)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eval_affine_epilogue_matches_separate_normalisation(precision, monkeypatch):
+    """Eval-mode generator (generate_synthetic_data.py:55): the BatchNorm-in-epilogue launches (fuse_out = 3) against
+    the same forward with the normalisation as a separate pass (the un-split launches take the fused route)."""
+    from pfa_gan import engine as E, kernels as K
+    torch.manual_seed(11)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=6, ngf=32).cuda().set_precision(precision)
+    with torch.no_grad():                     # non-trivial running statistics and affine parameters
+        for m in G.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    G.eval()
+    x = torch.rand((8, 3, 128, 128), device="cuda") * 2 - 1
+    fused_launches = []
+    real = K.gather_gemm
+
+    def spy(*a, **kw):
+        if kw.get("affine") is not None:
+            fused_launches.append(kw["affine"][2])
+        return real(*a, **kw)
+
+    monkeypatch.setattr(E.K, "gather_gemm", spy)
+    with torch.no_grad():
+        y_fused = G(x).float().cpu()
+    assert len(fused_launches) >= 2, "the large (un-split) layers take the affine epilogue"
+    monkeypatch.setattr(E._Engine, "_affine_ok", staticmethod(lambda *a: False))
+    with torch.no_grad():
+        y_plain = G(x).float().cpu()
+    tol = 2e-5 if precision == "fp32" else 2e-2
+    assert float((y_fused - y_plain).abs().max()) <= tol, float((y_fused - y_plain).abs().max())
