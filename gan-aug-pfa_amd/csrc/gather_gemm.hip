@@ -812,15 +812,15 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 
 // ---- tile configuration
 // shape 0: 128x128, 4 waves   shape 1: 128x64, 4 waves   shape 2: 256x16, 4 waves   shape 3: 256x128, 8 waves
+// shape 4: 256x64, 4 waves (knob 0 = 5: for 16 < n <= 64)
 // (two LDS buffers each).  pfa_set_knob(0, v): v = 4 forces shape 3 on launches with n >= 128, anything else is the
 // automatic choice.  pfa_set_knob(2, v): K-loop variant, 0 = default, v = 1..3 selects EARLY = v - 1.
 struct TileCfg { int id, bm, bn; };
-constexpr int DEFAULT_EARLY = 2;
 
 inline TileCfg choose_cfg(const GatherK& k) {
-    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 256, 128}};
+    static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 256, 128}, {4, 256, 64}};
     if (k.n <= 16) return cfgs[2];
-    if (k.n <= 64) return cfgs[1];
+    if (k.n <= 64) return g_knob[0] == 5 ? cfgs[4] : cfgs[1];
     // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
@@ -861,7 +861,10 @@ static int launch_gather(GatherK k, int classes, hipStream_t st) {
 
 template <typename T>
 static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t st) {
-    const int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : DEFAULT_EARLY;
+    // default K-loop per tile shape (tools/layer_bench.py): spreading the DMA pays on the 128x128 tile; the 128x64 tile
+    // (16 MFMAs per wave and K-step, three to four workgroups per CU) is 30-40 % faster with the plain reads-first loop
+    static const int default_early[] = {2, 0, 1, 1, 1};
+    const int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : default_early[cfg];
     switch (cfg * 3 + early) {
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
         case 1: return launch_gather<T, 128, 128, 2, 2, 1>(k, classes, st);
@@ -873,7 +876,9 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 7: case 8: return launch_gather<T, 256, 16, 4, 1, 1>(k, classes, st);
         case 9: return launch_gather<T, 256, 128, 4, 2, 0>(k, classes, st);
         case 10: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
-        default: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
+        case 11: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
+        case 12: return launch_gather<T, 256, 64, 4, 1, 0>(k, classes, st);
+        default: return launch_gather<T, 256, 64, 4, 1, 1>(k, classes, st);
     }
 }
 

@@ -24,6 +24,12 @@ L = [
  ("d4 dgrad",  K.CONV_S2, (32,32,[256]), 1024, (16,16), (16,16)),
  ("d3 dgrad",  K.CONV_S2, (64,64,[128]), 512, (32,32), (32,32)),
  ("d2 dgrad",  K.CONV_S2, (128,128,[64]), 256, (64,64), (64,64)),
+ # n = 64 layers
+ ("e1 fwd",    K.CONV_S2, (256,256,[8]), 64, (128,128), (128,128)),
+ ("d2 fwd",    K.TCONV_S2, (64,64,[128,128]), 64, (64,64), (128,128)),
+ ("e2 dgrad",  K.TCONV_S2, (64,64,[128]), 64, (64,64), (128,128)),
+ # n <= 16
+ ("c5 fwd",    K.CONV_S1, (31,31,[512]), 1, (30,30), (30,30)),
 ]
 def run(cfg):
     tile, loop = cfg
@@ -33,7 +39,7 @@ def run(cfg):
         srcs = [T(B,h,w,c) for c in cs]
         ctot = sum(cs)
         wgt = T(n,16,ctot)
-        o = torch.empty((B,ho,wo,n), device='cuda', dtype=dt)
+        o = torch.empty((B,ho,wo,K.pad_ch(n, dt)), device='cuda', dtype=dt)
         taps = 4 if mode == K.TCONV_S2 else 16
         classes = 4 if mode == K.TCONV_S2 else 1
         flop = 2.0*B*hq*wq*classes*n*taps*ctot
@@ -47,8 +53,8 @@ def run(cfg):
         us = e0.elapsed_time(e1)*1e3/reps
         out.append((name, us, flop/us/1e6))
     return out
-# (tile knob, loop knob): tile 0 auto / 4 = 256x128; loop 1 reads-first / 2 DMA-first / 3 DMA spread over the MFMAs
-res = {c: run(c) for c in ((0, 1), (0, 2), (0, 3), (4, 2))}
+# (tile knob, loop knob): tile 0 auto / 4 = 256x128 / 5 = 256x64 for n <= 64; loop 1 reads-first / 2 DMA-first / 3 DMA spread over the MFMAs
+res = {c: run(c) for c in ((0, 1), (0, 2), (0, 3))}
 print(f"{'layer':12s} " + "  ".join(f"cfg{c}: us   TF/s" for c in res))
 for i,(name, *_r) in enumerate(L):
     print(f"{name:12s} " + "  ".join(f"{res[c][i][1]:8.1f} {res[c][i][2]:6.0f}" for c in res))
