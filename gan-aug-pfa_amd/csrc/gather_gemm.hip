@@ -644,17 +644,30 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     const size_t row0 = (size_t)blockIdx.x * rpp * passes;
     const size_t plane = (size_t)pixels * n;
-    for (int ps = 0; ps < passes; ++ps) {
+    // All passes of the block are loaded together (the pass loop is unrolled, so every pass's read of slice k is in
+    // flight at once): a block is latency-, not bandwidth-bound.  The sum over slices stays in ascending k per element.
+    f32x4 v[FIN_PASSES];
+    bool live[FIN_PASSES];
+#pragma unroll
+    for (int ps = 0; ps < FIN_PASSES; ++ps) {
+        live[ps] = ps < passes && row0 + (size_t)ps * rpp + rsub < (size_t)pixels;
+        v[ps] = bv;
+    }
+    const float* src0 = slab + (row0 + rsub) * n + c0;
+    for (int k = 0; k < splitk; ++k) {
+#pragma unroll
+        for (int ps = 0; ps < FIN_PASSES; ++ps)
+            if (live[ps]) v[ps] += *(const f32x4*)(src0 + (size_t)ps * rpp * n + k * plane);
+    }
+#pragma unroll
+    for (int ps = 0; ps < FIN_PASSES; ++ps) {
+        if (!live[ps]) continue;
         const size_t row = row0 + (size_t)ps * rpp + rsub;
-        if (row >= (size_t)pixels) break;
-        const float* src = slab + row * n + c0;
-        f32x4 v = bv;
-        for (int k = 0; k < splitk; ++k) v += *(const f32x4*)(src + k * plane);
-        s += v;
-        q += v * v;
+        s += v[ps];
+        q += v[ps] * v[ps];
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = apply_act(v[e], act == PFA_ACT_TANH ? PFA_ACT_NONE : act, slope);
+        for (int e = 0; e < 4; ++e) o[e] = apply_act(v[ps][e], act == PFA_ACT_TANH ? PFA_ACT_NONE : act, slope);
         if (c0 < n1) store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
         else store4<T>(out2 + (row * ld2 + (c0 - n1)) * sizeof(T), o);
     }
