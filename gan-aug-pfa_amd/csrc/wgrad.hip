@@ -18,6 +18,7 @@
 #include "pfa_common.h"
 
 extern int g_knob[8];
+constexpr int WGRAD_DEFAULT_EARLY = 0;
 
 namespace {
 
@@ -36,6 +37,7 @@ struct WgradK {
     int jtot;        // 16 * gp
     int jtiles, itiles, nwg;
     int dbg;         // ablation bits (pfa_set_knob 1): 1 no atomics, 4 no MFMA, 8 no DMA
+    int early;       // K-loop order (pfa_set_knob 4: 1 = reads first, 2 = DMA first; 0 = default)
     float* slab;     // optional [msplit][tiles][BI*128] partial tiles (deterministic combine instead of atomics)
     int msplit;
 };
@@ -47,8 +49,18 @@ __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
     return q;
 }
 
-template <typename T, int BI, int WI, int WJ>
-__global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
+// Transpose read that hipcc cannot see through: the compiler drains vmcnt before any LDS read that may alias an LDS-DMA in
+// flight, which would serialise the next tile's DMA behind this tile's reads (same device as gather_gemm.hip's lds_read16).
+// The caller retires these with an explicit s_waitcnt lgkmcnt + pin().
+__device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
+
+template <typename T, int BI, int WI, int WJ, int EARLY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr bool BF = sizeof(T) == 2;
     constexpr int BJ = 128;
@@ -160,10 +172,12 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     // Phase 1 of a step: every LDS (transpose) read.  hipcc drains vmcnt before LDS reads that may alias an
     // LDS-DMA in flight, so the NEXT tile's DMA is issued only after these reads (phase 2) and then runs under
     // the MFMAs (phase 3) instead of in front of them.
-    auto read_frags = [&](int buf) {
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    auto read_frags = [&](int buf, bool raw) {
         if (p.dbg & 4) return;
         const char* dbase = smem + buf * STAGE;
         const char* gbase = dbase + D_BYTES;
+        const unsigned dbase_u = lds0 + buf * STAGE, gbase_u = dbase_u + D_BYTES;
 #pragma unroll
         for (int k32 = 0; k32 < 2; ++k32) {
 #pragma unroll
@@ -174,8 +188,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 for (int a = 0; a < FI; ++a) {
                     const int col = wi * TI + a * 16 + 4 * (lane & 3);
                     const int off = m * DROWB + (((col >> 3) ^ swz(m, RCD)) << 4) + ((col >> 2) & 1) * 8;
-                    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(dbase + off));
+                    bf16x4 t = raw ? lds_read_tr(dbase_u + off)
+                                   : __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                         (__attribute__((address_space(3))) bf16x4*)(dbase + off));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) af[k32][a][4 * e2 + e] = t[e];
                 }
@@ -183,8 +198,9 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
                 for (int b = 0; b < FJ; ++b) {
                     const int col = wj * TJ + b * 16 + 4 * (lane & 3);
                     const int off = m * GROWB + (((col >> 3) ^ swz(m, RCG)) << 4) + ((col >> 2) & 1) * 8;
-                    bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (__attribute__((address_space(3))) bf16x4*)(gbase + off));
+                    bf16x4 t = raw ? lds_read_tr(gbase_u + off)
+                                   : __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                                         (__attribute__((address_space(3))) bf16x4*)(gbase + off));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bfr[k32][b][4 * e2 + e] = t[e];
                 }
@@ -235,9 +251,25 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgradK p) {
     for (int ms = mbeg; ms < mend; ms += KM) {
         __syncthreads();              // tile `ms` has landed; everyone is done with the other buffer
         if constexpr (BF) {
-            read_frags(buf);
-            if (ms + KM < mend) stage(ms + KM, buf ^ 1);
-            mfma_frags();
+            if constexpr (EARLY) {
+                // DMA first: the next tile is in flight under both the transpose reads and the MFMAs
+                if (ms + KM < mend) stage(ms + KM, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(buf, true);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k32 = 0; k32 < 2; ++k32) {
+#pragma unroll
+                    for (int a = 0; a < FI; ++a) pin(af[k32][a]);
+#pragma unroll
+                    for (int b = 0; b < FJ; ++b) pin(bfr[k32][b]);
+                }
+                mfma_frags();
+            } else {
+                read_frags(buf, false);
+                if (ms + KM < mend) stage(ms + KM, buf ^ 1);
+                mfma_frags();
+            }
         } else {
             if (ms + KM < mend) stage(ms + KM, buf ^ 1);
             compute_f32(buf);
@@ -320,8 +352,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
     else atomicAdd(dst, tot);
 }
 
-template <typename T, int BI, int WI, int WJ>
-int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
+template <typename T, int BI, int WI, int WJ, int EARLY>
+int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     constexpr int KM = sizeof(T) == 2 ? 64 : 32;
     constexpr size_t lds = 2 * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
     k.jtiles = (k.jtot + 127) / 128;
@@ -330,12 +362,12 @@ int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
     dim3 grid(k.nwg);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     k.msplit = msplit;
-    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY>), grid, dim3(256), lds, st, k);
     PFA_LAUNCHED("k_wgrad");
     if (k.slab) {
         hipLaunchKernelGGL((k_wgrad_reduce<BI, WI, WJ>),
@@ -343,6 +375,12 @@ int launch_wgrad(WgradK k, int msplit, hipStream_t st) {
         PFA_LAUNCHED("k_wgrad_reduce");
     }
     return 0;
+}
+
+template <typename T, int BI, int WI, int WJ>
+int launch_wgrad(const WgradK& k, int msplit, hipStream_t st) {
+    if (k.early && sizeof(T) == 2) return launch_wgrad_v<T, BI, WI, WJ, 1>(k, msplit, st);
+    return launch_wgrad_v<T, BI, WI, WJ, 0>(k, msplit, st);
 }
 
 }  // namespace
@@ -374,6 +412,7 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     if (hw == 1) k.magic_hw = 0xffffffffu;
     if (a->wq == 1) k.magic_wq = 0xffffffffu;
     k.dbg = g_knob[1];
+    k.early = g_knob[4] == 1 ? 0 : g_knob[4] == 2 ? 1 : WGRAD_DEFAULT_EARLY;
     k.jtot = 16 * k.gp;
     const int km = a->dtype == PFA_BF16 ? 64 : 32;
     k.step_img = km / hw;

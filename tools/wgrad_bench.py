@@ -19,6 +19,9 @@ L = [("e1", (128,128,[64]), (256,256,[8]), 2, [64], [3]),
      ("d3", (32,32,[256,256]), (64,64,[128]), 2, [256,256], [128]),
      ("d2", (64,64,[128,128]), (128,128,[64]), 2, [128,128], [64]),
      ("d1", (128,128,[64,64]), (256,256,[8]), 2, [64,64], [3])]
+import os
+from pfa_gan import _lib as _L
+_L.lib().pfa_set_knob(4, int(os.environ.get("WG_LOOP", "0")))     # knob 4: 1 reads first, 2 DMA first
 tot=0
 for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in L:
     d=[T(B,dh,dw,c) for c in dcs]; g=[T(B,gh,gw,c) for c in gcs]
