@@ -42,6 +42,7 @@ struct GatherK {
     int act;
     float slope;
     int mtiles, ntiles, nwg;
+    int classes, order;      // parity classes (4 for PFA_TCONV_S2), work-list order (kernel comment)
     int wide, spt, sp1;      // wide path: K-steps per tap, K-steps of a tap that come from src1
     int dbg;                 // ablation bits (pfa_set_knob 1): 1 no output stores, 2 no stats, 4 no MFMA, 8 no DMA
     // fused activation / BatchNorm backward on one output (dgrad launches): dy = act1'(y)*acc + act2'(y)*g2
@@ -134,11 +135,29 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WM, wn = wave / WM;
-    // work list order: n-tile fastest (blocks sharing an activation tile are neighbours), then m-tile, then class/slice
+    // Work list: each XCD (private L2) takes one contiguous chunk of it, so the slowest index decides what an XCD shares.
+    //   order 0: n-tile, m-tile, K slice, parity class (slowest): an XCD holds one class / slice - weights fetched once,
+    //            the input once per class or slice;
+    //   order 1: n-tile, K slice, class, m-tile (slowest): an XCD holds a range of pixels with ALL their classes and
+    //            slices - the input is fetched once, the weights once per XCD;
+    //   order 2: m-tile, K slice, class, n-tile (slowest): an XCD holds a range of output channels - the weights are
+    //            fetched once, the input once per XCD.
+    // The host picks the order with the fewest fetched bytes (choose_order); results do not depend on it.
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);
-    const int nt = wid % p.ntiles; wid /= p.ntiles;
-    const int mt = wid % p.mtiles; wid /= p.mtiles;
-    const int split = wid % p.splitk, cls = wid / p.splitk;
+    int nt, mt, split, cls;
+    if (p.order == 1) {
+        nt = wid % p.ntiles; wid /= p.ntiles;
+        split = wid % p.splitk; wid /= p.splitk;
+        cls = wid % p.classes; mt = wid / p.classes;
+    } else if (p.order == 2) {
+        mt = wid % p.mtiles; wid /= p.mtiles;
+        split = wid % p.splitk; wid /= p.splitk;
+        cls = wid % p.classes; nt = wid / p.classes;
+    } else {
+        nt = wid % p.ntiles; wid /= p.ntiles;
+        mt = wid % p.mtiles; wid /= p.mtiles;
+        split = wid % p.splitk; cls = wid / p.splitk;
+    }
     const int py = cls >> 1, px = cls & 1;
     const int m0 = mt * BM, n0 = nt * BN;
     const char* zero = (const char*)g_pfa_zero_page;
@@ -854,11 +873,32 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     return classes * ((k.M + bm - 1) / bm);
 }
 
+// Elements each order pulls through the 8 private L2s, to first order (an operand part an XCD needs is fetched by that XCD
+// once; A = input elements, W = weight elements, C = parity classes, S = K slices, P = S*C "planes" of m x n tiles):
+//   order 0 (plane-major): a plane reads the whole input and 1/P of the weights; with P < 8 a plane is cut over 8/P XCDs
+//                          by pixel range          ->  A*min(P, 8) + W*max(1, 8/P)
+//   order 1 (pixel-major): each XCD reads its pixels once and all the weights   ->  A + 8*W
+//   order 2 (channel-major, needs >= 8 n-tiles): all pixels, its share of the weights   ->  8*A + W
+// Measured with rocprofv3 FETCH_SIZE inside a step (tools/step_traffic.py): d2 forward 472 -> see DESIGN section 6.
+static int choose_order(const GatherK& k) {
+    if (g_knob[5] >= 1 && g_knob[5] <= 3) return g_knob[5] - 1;
+    const double A = (double)k.nb * k.hs * k.ws * k.ctot;
+    const double W = (double)k.n * 16 * k.ctot;
+    const double P = (double)k.splitk * k.classes;
+    const double cost0 = A * (P < 8.0 ? P : 8.0) + W * (P < 8.0 ? 8.0 / P : 1.0);
+    const double cost1 = A + 8.0 * W;
+    const double cost2 = k.ntiles >= 8 ? 8.0 * A + W : 1e300;
+    if (cost2 < cost0 && cost2 < cost1) return 2;
+    return cost1 < cost0 ? 1 : 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int EARLY>
 static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.mtiles = (k.M + BM - 1) / BM;
     k.ntiles = (k.n + BN - 1) / BN;
     k.nwg = k.mtiles * k.ntiles * classes * k.splitk;
+    k.classes = classes;
+    k.order = choose_order(k);
     dim3 grid(k.nwg);
     const size_t lds = 2 * (BM * 128 + BN * 128);
     static bool attr_done = false;
