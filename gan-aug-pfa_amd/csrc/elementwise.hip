@@ -105,6 +105,22 @@ __global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const fl
 }
 
 // ------------------------------------------------------------------ normalise + dual activation
+// Per-lane channel coefficients: CH consecutive floats starting at c0 (16-byte aligned), or a constant when the array
+// is absent.  ONE uniform branch and vector loads: written element by element (`p ? p[c0+e] : k`) the compiler emits a
+// separately branched, serialised load per element, ~1 us each - 15 us of fixed latency per launch.
+template <int CH> __device__ __forceinline__ void load_coef(const float* __restrict__ p, int c0, float dflt, float* out) {
+    if (p) {
+#pragma unroll
+        for (int e = 0; e < CH; e += 4) {
+            const f32x4 t = *(const f32x4*)(p + c0 + e);
+            out[e] = t[0]; out[e + 1] = t[1]; out[e + 2] = t[2]; out[e + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CH; ++e) out[e] = dflt;
+    }
+}
+
 // The grid is sized so that (threads in the grid) % (chunks per row) == 0: a lane then always lands on the same
 // channel chunk and keeps its scale/shift in registers for the whole grid-stride loop.
 template <typename T>
@@ -115,11 +131,8 @@ __global__ __launch_bounds__(256) void k_bn_act(const T* __restrict__ raw, int64
     const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c0 = (int)(first % cpr) * CH;
     float sc[CH], sh[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) {
-        sc[e] = scale ? scale[c0 + e] : 1.f;
-        sh[e] = scale ? shift[c0 + e] : 0.f;
-    }
+    load_coef<CH>(scale, c0, 1.f, sc);
+    load_coef<CH>(scale ? shift : nullptr, c0, 0.f, sh);
     for (int64_t idx = first; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
         Chunk<T> x, l, r;
         x.load(raw + idx * CH);
@@ -151,12 +164,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* __restrict__ raw
     const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
     const int c0 = col * CH;
     float sc[CH], sh[CH], mu[CH], is[CH], s_dy[CH], s_dyx[CH];
+    load_coef<CH>(scale, c0, 1.f, sc);
+    load_coef<CH>(scale ? shift : nullptr, c0, 0.f, sh);
+    load_coef<CH>(mean, c0, 0.f, mu);
+    load_coef<CH>(mean ? invstd : nullptr, c0, 1.f, is);
 #pragma unroll
     for (int e = 0; e < CH; ++e) {
-        sc[e] = scale ? scale[c0 + e] : 1.f;
-        sh[e] = scale ? shift[c0 + e] : 0.f;
-        mu[e] = mean ? mean[c0 + e] : 0.f;
-        is[e] = mean ? invstd[c0 + e] : 1.f;
         s_dy[e] = 0.f;
         s_dyx[e] = 0.f;
     }

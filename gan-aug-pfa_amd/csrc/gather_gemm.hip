@@ -50,6 +50,9 @@ struct GatherK {
     const char* fuse_raw;
     const char* fuse_g2;
     const float *fuse_scale, *fuse_shift, *fuse_mean, *fuse_invstd;
+    int fuse_nreal;          // entries of the fuse_* coefficient arrays (the fused output's real channel count)
+    int bias_unaligned;      // bias pointer not 16-byte aligned: element-wise loads
+    int coef_unaligned;      // likewise for the fuse_* arrays
     int stat_col0, stat_n;   // statistics cover output columns [stat_col0, stat_col0 + stat_n), row length stat_n
 };
 
@@ -510,11 +513,19 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nbase + 4 <= p.n && !(p.bias_unaligned)) {
+                const f32x4 b4 = *(const f32x4*)(p.bias + nbase);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[r] = b4[r];
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (nbase + r < p.n) bv[r] = p.bias[nbase + r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float bv = (nbase + r < p.n) ? p.bias[nbase + r] : 0.f;
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b][r] += mval[b] ? bv : 0.f;   // rows >= M stay exact zeros
+                for (int b = 0; b < FM; ++b) acc[a][b][r] += mval[b] ? bv[r] : 0.f;   // rows >= M stay exact zeros
             }
         }
     }
@@ -533,13 +544,30 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fs[a][r] = 0.f; fq[a][r] = 0.f; }
             if (!mine || col >= ld) continue;
-            float sc[4], sh[4], mu[4], is[4];
+            // coefficients of 4 consecutive channels: uniform branches + one 16-byte load per array (element-wise
+            // `ptr ? ptr[i] : k` compiles to a branched, serialised load per element).  The arrays hold the layer's real
+            // channel count, which is a multiple of 4 wherever a norm layer exists; a ragged tail reads element-wise.
+            float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f};
+            const bool whole = col + 4 <= p.fuse_nreal && !p.coef_unaligned;
+            if (p.fuse_scale) {
+                if (whole) {
+                    const f32x4 a4 = *(const f32x4*)(p.fuse_scale + col), b4 = *(const f32x4*)(p.fuse_shift + col);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sc[r] = p.fuse_scale ? p.fuse_scale[col + r] : 1.f;
-                sh[r] = p.fuse_scale ? p.fuse_shift[col + r] : 0.f;
-                mu[r] = p.fuse_mean ? p.fuse_mean[col + r] : 0.f;
-                is[r] = p.fuse_mean ? p.fuse_invstd[col + r] : 1.f;
+                    for (int r = 0; r < 4; ++r) { sc[r] = a4[r]; sh[r] = b4[r]; }
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < p.fuse_nreal) { sc[r] = p.fuse_scale[col + r]; sh[r] = p.fuse_shift[col + r]; }
+                }
+            }
+            if (p.fuse_mean) {
+                if (whole) {
+                    const f32x4 a4 = *(const f32x4*)(p.fuse_mean + col), b4 = *(const f32x4*)(p.fuse_invstd + col);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { mu[r] = a4[r]; is[r] = b4[r]; }
+                } else {
+                    for (int r = 0; r < 4; ++r)
+                        if (col + r < p.fuse_nreal) { mu[r] = p.fuse_mean[col + r]; is[r] = p.fuse_invstd[col + r]; }
+                }
             }
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
@@ -567,12 +595,19 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+            float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nbase + 4 <= p.n && !p.coef_unaligned) {   // one 16-byte load per array (see the note in the backward block)
+                const f32x4 a4 = *(const f32x4*)(p.fuse_scale + nbase), b4 = *(const f32x4*)(p.fuse_shift + nbase);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[r] = a4[r]; sh[r] = b4[r]; }
+            } else {
+                for (int r = 0; r < 4; ++r)
+                    if (nbase + r < p.n) { sc[r] = p.fuse_scale[nbase + r]; sh[r] = p.fuse_shift[nbase + r]; }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const bool nv = nbase + r < p.n;
-                const float sc = nv ? p.fuse_scale[nbase + r] : 0.f, sh = nv ? p.fuse_shift[nbase + r] : 0.f;
 #pragma unroll
-                for (int b = 0; b < FM; ++b) acc[a][b][r] = mval[b] ? acc[a][b][r] * sc + sh : 0.f;
+                for (int b = 0; b < FM; ++b) acc[a][b][r] = mval[b] ? acc[a][b][r] * sc[r] + sh[r] : 0.f;
             }
         }
     }
@@ -816,6 +851,12 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.fuse_raw = (const char*)a->fuse_raw; k.fuse_g2 = (const char*)a->fuse_g2;
     k.fuse_scale = a->fuse_scale; k.fuse_shift = a->fuse_shift; k.fuse_mean = a->fuse_mean; k.fuse_invstd = a->fuse_invstd;
     k.stat_col0 = 0; k.stat_n = a->n;
+    // vector (16-byte) loads of per-channel coefficients need aligned arrays; anything else takes the element-wise path
+    auto misaligned = [](const void* q) { return q && ((uintptr_t)q & 15u); };
+    k.bias_unaligned = misaligned(a->bias) ? 1 : 0;
+    const bool coef_bad = misaligned(a->fuse_scale) || misaligned(a->fuse_shift) || misaligned(a->fuse_mean) || misaligned(a->fuse_invstd);
+    k.fuse_nreal = a->fuse_out == 1 ? (a->n < a->n1 ? a->n : a->n1) : a->fuse_out == 2 ? a->n - a->n1 : a->n;
+    k.coef_unaligned = coef_bad ? 1 : 0;
     if (a->fuse_out == 3) {
         PFA_REQUIRE(a->fuse_scale && a->fuse_shift, "pfa_gather_gemm: the affine epilogue needs scale and shift");
         PFA_REQUIRE(a->n1 >= a->n && a->bias == nullptr && a->psum == nullptr && a->act != PFA_ACT_TANH &&
