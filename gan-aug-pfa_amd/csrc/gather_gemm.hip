@@ -729,13 +729,21 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = q[e]; }
     __syncthreads();
+    for (int off = rpp >> 1; off > 0; off >>= 1) {       // fixed-shape tree over the row groups (rpp is a power of two)
+        if (rsub < off) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][tid][e] += red[0][tid + off * cpr][e];
+                red[1][tid][e] += red[1][tid + off * cpr][e];
+            }
+        }
+        __syncthreads();
+    }
     if (tid < cpr) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float a = 0.f, b = 0.f;
-            for (int r = 0; r < rpp; ++r) { a += red[0][r * cpr + tid][e]; b += red[1][r * cpr + tid][e]; }
-            psum[(size_t)blockIdx.x * n + tid * 4 + e] = a;
-            psq[(size_t)blockIdx.x * n + tid * 4 + e] = b;
+            psum[(size_t)blockIdx.x * n + tid * 4 + e] = red[0][tid][e];
+            psq[(size_t)blockIdx.x * n + tid * 4 + e] = red[1][tid][e];
         }
     }
 }

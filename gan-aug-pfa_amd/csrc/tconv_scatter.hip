@@ -154,6 +154,14 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
     //      NCO == 8: column = tap*8 + co      -> tap = 2a + (kk >> 1),   co = 4*(kk&1) + r   (ky = a >> 1)
     // Output rows of one parity use two ky values; each pass writes that half of Y (fp32) and gathers from it.
     const int HO = 2 * p.hs, WO = 2 * p.ws;
+    float bv[NCO];                       // bias of the real channels, fetched once (uniform addresses: scalar loads)
+#pragma unroll
+    for (int e = 0; e < NCO; ++e) bv[e] = 0.f;
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < NCO; ++e)
+            if (e < p.n) bv[e] = p.bias[e];
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         // pass 0: ky in {1, 3} -> even output rows;  pass 1: ky in {0, 2} -> odd output rows
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
                 for (int e = 0; e < CH; ++e) {
                     const int c = e0 + e;
                     float t = 0.f;                           // pad lanes are exact zeros
-                    if (c < NCO && c < p.n) t = apply_act(v[c < NCO ? c : 0] + (p.bias ? p.bias[c] : 0.f), p.act, p.slope);
+                    if (c < NCO && c < p.n) t = apply_act(v[c < NCO ? c : 0] + bv[c < NCO ? c : 0], p.act, p.slope);
                     o.v[e] = t;
                 }
                 o.store(op + e0);
