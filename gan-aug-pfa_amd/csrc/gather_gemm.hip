@@ -906,6 +906,9 @@ inline TileCfg choose_cfg(const GatherK& k) {
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
     if (g_knob[0] == 4) return cfgs[3];
+    if (g_knob[0] == 6) return cfgs[1];              // experiment: 128x64 everywhere
+    // (128x64 for unsplit launches with one 128x128 workgroup per CU: -14 % on e3/c3 forward in isolation, nothing in
+    //  the step - not enabled.)
     return cfgs[0];
 }
 

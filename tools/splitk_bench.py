@@ -3,6 +3,9 @@ import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import torch
 from pfa_gan import kernels as K
+import os
+from pfa_gan import _lib as _L
+_L.lib().pfa_set_knob(0, int(os.environ.get('TILE', '0')))      # 6: 128x64 tile everywhere
 B=16; dt=torch.bfloat16; ws=K.Workspace(torch.device('cuda'))
 def T(*shape): return torch.randn(shape, device='cuda').to(dt)
 L = [("e3/c3 fwd", K.CONV_S2, (64,64,[128]), 256, (32,32), (32,32)),
