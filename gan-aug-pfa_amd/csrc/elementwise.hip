@@ -451,60 +451,7 @@ __global__ __launch_bounds__(256) void k_shadow_tr(const float* __restrict__ mas
     }
 }
 
-// Batched form: one launch covers every layer of a network; a block finds its layer in the descriptor table.
 constexpr int SHADOW_ELEMS = 256 * 8;
-__device__ __forceinline__ int find_layer(const pfa_shadow_desc* d, int n, int blk, bool tr) {
-    int l = 0;
-    while (l + 1 < n && (tr ? d[l + 1].tr_blk0 : d[l + 1].same_blk0) <= blk) ++l;
-    return l;
-}
-template <typename T>
-__global__ __launch_bounds__(256) void k_shadow_same_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
-    const int l = find_layer(descs, n, blockIdx.x, false);
-    const pfa_shadow_desc d = descs[l];
-    const int cr = d.c1r + d.c2r, cp_tot = d.c1p + d.c2p;
-    const int64_t total = (int64_t)d.rows * 16 * cp_tot;
-    const int64_t base = (int64_t)(blockIdx.x - d.same_blk0) * SHADOW_ELEMS;
-    T* same = (T*)d.same;
-#pragma unroll
-    for (int k = 0; k < SHADOW_ELEMS / 256; ++k) {
-        const int64_t idx = base + k * 256 + threadIdx.x;
-        if (idx >= total) break;
-        const int cp = (int)(idx % cp_tot);
-        const int64_t rt = idx / cp_tot;
-        const int c = real_channel(cp, d.c1r, d.c1p, d.c2r);
-        same[idx] = from_f32<T>(c >= 0 ? d.master[rt * cr + c] : 0.f);
-    }
-}
-template <typename T>
-__global__ __launch_bounds__(256) void k_shadow_tr_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
-    __shared__ float tile[32][33];
-    const int l = find_layer(descs, n, blockIdx.x, true);
-    const pfa_shadow_desc d = descs[l];
-    const int cr = d.c1r + d.c2r, cp_tot = d.c1p + d.c2p;
-    const int tc = (cp_tot + 31) / 32, tr_ = (d.rows_p + 31) / 32;
-    int lb = blockIdx.x - d.tr_blk0;
-    const int cp0 = (lb % tc) * 32; lb /= tc;
-    const int r0 = (lb % tr_) * 32;
-    const int tap = lb / tr_;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    T* trp = (T*)d.tr;
-    for (int k = 0; k < 4; ++k) {
-        const int r = r0 + ty + 8 * k, cp = cp0 + tx;
-        float v = 0.f;
-        if (r < d.rows && cp < cp_tot) {
-            const int c = real_channel(cp, d.c1r, d.c1p, d.c2r);
-            if (c >= 0) v = d.master[((size_t)r * 16 + tap) * cr + c];
-        }
-        tile[ty + 8 * k][tx] = v;
-    }
-    __syncthreads();
-    for (int k = 0; k < 4; ++k) {
-        const int cp = cp0 + ty + 8 * k, r = r0 + tx;
-        if (cp < cp_tot && r < d.rows_p) trp[((size_t)cp * 16 + tap) * d.rows_p + r] = from_f32<T>(tile[tx][ty + 8 * k]);
-    }
-}
-
 // ------------------------------------------------------------------ NCHW float32 <-> NHWC T
 template <typename T>
 __global__ __launch_bounds__(256) void k_pack_nhwc(const float* __restrict__ src, int n, int c, int64_t hw, int cp,
@@ -525,6 +472,64 @@ __global__ __launch_bounds__(256) void k_unpack_nchw(const T* __restrict__ src, 
         const int ch = (int)(t % c);
         const int64_t img = t / c;
         dst[idx] = to_f32(src[(img * hw + off) * cp + ch]);
+    }
+}
+
+
+// Both shadows of every layer in ONE launch: a workgroup reads a 64 (rows) x 64 (padded channels) tile of one tap from the
+// fp32 master once (256-byte coalesced rows), keeps it in LDS and writes `same` (rows of 64 channels) and `tr` (rows of 64
+// master-rows) with 16-byte stores.  The layer of a block is found by one ballot over the descriptor table (a serial scan
+// costs a load latency per layer and block).  335 MB instead of 502 MB for the generator, no per-element div/mod.
+constexpr int SH_TILE = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
+    constexpr int CH = ElemTraits<T>::CH;
+    constexpr int GROUPS = SH_TILE / CH;                  // 16-byte groups per tile row
+    __shared__ float tile[SH_TILE][SH_TILE + 1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int mine = lane < n ? descs[lane].tr_blk0 : 0x7fffffff;
+    const int l = __popcll(__ballot(mine <= (int)blockIdx.x)) - 1;
+    const pfa_shadow_desc d = descs[l];
+    const int cr = d.c1r + d.c2r, cp_tot = d.c1p + d.c2p;
+    const int tc = (cp_tot + SH_TILE - 1) / SH_TILE, trn = (d.rows_p + SH_TILE - 1) / SH_TILE;
+    int lb = (int)blockIdx.x - d.tr_blk0;
+    const int cp0 = (lb % tc) * SH_TILE; lb /= tc;
+    const int r0 = (lb % trn) * SH_TILE;
+    const int tap = lb / trn;
+    {
+        const int tx = tid & 63, ty = tid >> 6;
+        const int cp = cp0 + tx;
+        const int c = cp < cp_tot ? real_channel(cp, d.c1r, d.c1p, d.c2r) : -1;
+#pragma unroll
+        for (int k = 0; k < SH_TILE / 4; ++k) {
+            const int r = r0 + ty + 4 * k;
+            tile[ty + 4 * k][tx] = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
+        }
+    }
+    __syncthreads();
+    T* same = (T*)d.same;
+    T* trp = (T*)d.tr;
+#pragma unroll
+    for (int it = tid; it < SH_TILE * GROUPS; it += 256) {
+        const int line = it / GROUPS, g = it % GROUPS;
+        if (same) {                                         // line = master row, g = channel group
+            const int r = r0 + line, cpb = cp0 + g * CH;
+            if (r < d.rows && cpb < cp_tot) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) o.v[e] = tile[line][g * CH + e];
+                o.store(same + ((size_t)r * 16 + tap) * cp_tot + cpb);
+            }
+        }
+        if (trp) {                                          // line = padded channel, g = master-row group
+            const int cp = cp0 + line, rb = r0 + g * CH;
+            if (cp < cp_tot && rb < d.rows_p) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < CH; ++e) o.v[e] = tile[g * CH + e][line];
+                o.store(trp + ((size_t)cp * 16 + tap) * d.rows_p + rb);
+            }
+        }
     }
 }
 
@@ -756,22 +761,19 @@ extern "C" int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p
 extern "C" int pfa_shadow_blocks(int rows, int c1p, int c2p, int rows_p, int* same_blocks, int* tr_blocks) {
     PFA_REQUIRE(rows > 0 && c1p > 0 && c2p >= 0 && rows_p >= rows && same_blocks && tr_blocks, "pfa_shadow_blocks: bad arguments");
     const int cp = c1p + c2p;
-    *same_blocks = (int)(((int64_t)rows * 16 * cp + SHADOW_ELEMS - 1) / SHADOW_ELEMS);
-    *tr_blocks = ((cp + 31) / 32) * ((rows_p + 31) / 32) * 16;
+    *same_blocks = (int)(((int64_t)rows * 16 * cp + SHADOW_ELEMS - 1) / SHADOW_ELEMS);      // (unused by the fused launch)
+    *tr_blocks = ((cp + SH_TILE - 1) / SH_TILE) * ((rows_p + SH_TILE - 1) / SH_TILE) * 16;     // 64x64 tiles x 16 taps
     return 0;
 }
 
 extern "C" int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int same_blocks, int tr_blocks,
                                        int dtype, pfa_stream s) {
-    PFA_REQUIRE(descs_dev && n > 0 && same_blocks > 0 && tr_blocks > 0, "pfa_weight_shadow_batch: bad arguments");
+    PFA_REQUIRE(descs_dev && n > 0 && n <= 64 && tr_blocks > 0, "pfa_weight_shadow_batch: bad arguments (at most 64 layers per table)");
+    (void)same_blocks;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(k_shadow_same_batch<bf16_t>, dim3(same_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
-               hipLaunchKernelGGL(k_shadow_same_batch<float>, dim3(same_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
-    PFA_LAUNCHED("k_shadow_same_batch");
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(k_shadow_tr_batch<bf16_t>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
-               hipLaunchKernelGGL(k_shadow_tr_batch<float>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
-    PFA_LAUNCHED("k_shadow_tr_batch");
+               hipLaunchKernelGGL(k_shadow_fused_batch<bf16_t>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
+               hipLaunchKernelGGL(k_shadow_fused_batch<float>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
+    PFA_LAUNCHED("k_shadow_fused_batch");
     return 0;
 }
 

@@ -231,8 +231,9 @@ int pfa_adam_tick(int32_t* step_dev, pfa_stream s);
  *   tr  : [c1p+c2p][16][rows_p] in `dtype` (rows of pad channels zero).   Either may be NULL. */
 int pfa_weight_shadow(const float* master, int rows, int c1r, int c1p, int c2r, int c2p, int rows_p, int dtype,
                       void* same, void* tr, pfa_stream s);
-/* All layers of a network in two launches: a device-resident table of descriptors (same fields as above, plus the
- * first block index of each layer in the two launches, from pfa_shadow_blocks; layers in ascending block order). */
+/* All layers of a network (at most 64) in one launch that reads each master once and writes both shadows: a
+ * device-resident table of descriptors (same fields as above, plus the first block index of each layer - tr_blk0, the
+ * running sum of pfa_shadow_blocks' tr_blocks; layers in ascending block order; same / tr may be NULL). */
 typedef struct pfa_shadow_desc {
     const float* master;
     void* same;

@@ -417,3 +417,26 @@ def test_eval_affine_epilogue_matches_separate_normalisation(precision, monkeypa
         y_plain = G(x).float().cpu()
     tol = 2e-5 if precision == "fp32" else 2e-2
     assert float((y_fused - y_plain).abs().max()) <= tol, float((y_fused - y_plain).abs().max())
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_shadow_launch_equals_per_layer_kernels(precision):
+    """pfa_weight_shadow_batch (one launch: 64x64 tiles, both layouts) against pfa_weight_shadow layer by layer, bit for
+    bit, on networks with ragged channel counts (3/6-channel image layers, virtual-concat decoder inputs, a 1-channel
+    output conv)."""
+    from pfa_gan import kernels as K
+    torch.manual_seed(5)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=24).cuda().set_precision(precision)
+    D = pfa_gan.NLayerDiscriminator(6, ndf=40).cuda().set_precision(precision)
+    for eng in (G.engine(), D.engine(in_split=[3, 3])):
+        for L in eng.layers:
+            L.same.fill_(7.0)
+            L.tr.fill_(7.0)
+        eng.refresh_shadows(force=True)
+        for L in eng.layers:
+            (c1r, c1p), (c2r, c2p) = L.cparts[0], (L.cparts[1] if len(L.cparts) > 1 else (0, 0))
+            same, tr = torch.full_like(L.same, 5.0), torch.full_like(L.tr, 5.0)
+            K.weight_shadow(eng.flat.seg(eng.flat.data, L.w), L.rows, c1r, c1p, c2r, c2p, L.rows_p, same, tr)
+            torch.cuda.synchronize()
+            assert torch.equal(L.same, same), f"{L.name if hasattr(L, 'name') else L}: same"
+            assert torch.equal(L.tr, tr), f"{L.name if hasattr(L, 'name') else L}: tr"
