@@ -42,6 +42,8 @@ def parse():
                          "measured faster: the graph executor does not run the forked side-stream branch concurrently)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
+    ap.add_argument("--no-early-real", action="store_true",
+                    help="D(real) of a step waits for the whole previous step (A/B switch for inputs_resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -202,8 +204,9 @@ def main():
     torch.manual_seed(0)                             # identical default init on every rank (reference init, a12)
     gen = pfa_gan.UNetGenerator(3, 3).cuda()
     disc = pfa_gan.NLayerDiscriminator(6).cuda()
+    # inputs_resident: the batches below are packed and complete in HBM before the first step (the bench contract)
     trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph=args.graph,
-                                 overlap=not args.no_overlap)
+                                 overlap=not args.no_overlap, inputs_resident=not args.no_early_real)
     if world > 1:                                    # rank 0's parameters and buffers are the job's
         for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
             torch.distributed.broadcast(t, 0)
@@ -216,6 +219,7 @@ def main():
         a = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
         b = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
         pool.append((trainer.pack(a), trainer.pack(b)))
+    torch.cuda.synchronize()                         # resident: every batch is complete before the first step
 
     def barrier():
         if world > 1:

@@ -97,7 +97,11 @@ class GanTrainer:
     """Owns the engines, contexts and optimizers of one (generator, discriminator) pair on one GPU."""
 
     def __init__(self, gen, disc, opt_g=None, opt_d=None, precision="bf16", lambda_l1=LAMBDA_L1, process_group=None,
-                 use_graph=False, overlap=True):
+                 use_graph=False, overlap=True, inputs_resident=False):
+        """inputs_resident: the caller guarantees that the (packed) batches handed to step_packed() are complete in
+        device memory before the call - e.g. a pool of resident batches, or batches produced on a stream the caller
+        has synchronised.  The D(real) pass of a step then no longer waits for the previous step's generator update
+        (see _d_phase)."""
         self.gen, self.disc = gen, disc
         self.dtype = resolve_dtype(precision)
         nc_a = gen.input_nc
@@ -126,6 +130,10 @@ class GanTrainer:
         self.side = torch.cuda.Stream(device=dev) if overlap else None
         self.side2 = torch.cuda.Stream(device=dev) if overlap else None
         self._ev_real_fwd = torch.cuda.Event() if overlap else None
+        self._ev_d_free = torch.cuda.Event() if overlap else None     # D engine idle, D weights final for this step
+        self._d_free_recorded = False
+        self.inputs_resident = bool(inputs_resident)
+        self._loss_real = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = None
         self._static = None
         self.G.refresh_shadows(force=True)
@@ -152,14 +160,26 @@ class GanTrainer:
         # the second gradient arena; main: G forward -> D(fake) forward -> D(fake) dgrad/BatchNorm chain; side2: D(fake)'s
         # parameter gradients.  D(real)'s forward finishes before D(fake)'s starts, so the BatchNorm running buffers are
         # updated in the reference's order (real, then fake: train_gan.py:57,59).
+        #
+        # D(real) needs the discriminator's weights (final since the Adam(D) of the previous step), its engine state
+        # (free once the previous step's G-phase D backward is done: _ev_d_free) and the inputs - nothing of the
+        # previous step's generator backward / Adam(G) / shadow refresh / gradient zero-fills.  With inputs_resident
+        # the side stream therefore waits for _ev_d_free only, and this step's D(real) runs under the HBM-bound tail of
+        # the previous step instead of after it.  Its loss goes to a slot of its own (the main stream zeroes `losses`
+        # later than the side stream may already have added to it) and its gradient arena is zeroed on the side stream.
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
-        self.opt_d.zero_grad()
-        self.side.wait_stream(main)
+        if self.inputs_resident and self._d_free_recorded and not graph_safe:
+            self.side.wait_event(self._ev_d_free)
+        else:
+            self.side.wait_stream(main)
+        K.fill_zero(garena)
         with torch.cuda.stream(self.side):
+            K.fill_zero(garena2)
+            K.fill_zero(self._loss_real)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-            K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+            K.bce_logits(lr, 1.0, 0.5, 0.5, self._loss_real, dl_r)
             self._ev_real_fwd.record(self.side)
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True)
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
@@ -170,6 +190,7 @@ class GanTrainer:
         Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side2)
         main.wait_stream(self.side)
         main.wait_stream(self.side2)
+        self.losses[0:1].add_(self._loss_real)
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
@@ -181,6 +202,9 @@ class GanTrainer:
         dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
         K.bce_logits(lg, 1.0, 1.0, 1.0, self.losses[1:2], dl_g)
         dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
+        if self._ev_d_free is not None and not graph_safe:
+            self._ev_d_free.record(torch.cuda.current_stream())    # the next step's D(real) may start from here
+            self._d_free_recorded = True
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
         K.l1_tanh_bwd(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self.losses[1:2], dpre)
         garena = self.opt_g.flat().grad

@@ -440,3 +440,31 @@ def test_fused_shadow_launch_equals_per_layer_kernels(precision):
             torch.cuda.synchronize()
             assert torch.equal(L.same, same), f"{L.name if hasattr(L, 'name') else L}: same"
             assert torch.equal(L.tr, tr), f"{L.name if hasattr(L, 'name') else L}: tr"
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_fused_step_with_resident_inputs_matches_reference(golden, case):
+    """GanTrainer(inputs_resident=True): D(real) of step i+1 starts as soon as the discriminator is free in step i (under
+    the generator's Adam / shadow refresh) instead of after it.  Same goldens as the default schedule: losses of every
+    step (the real-pass loss travels through its own slot) and the final state."""
+    name, nd, ngf, ndf, n, h, steps = case
+    z = golden("step")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+    load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+    tr = pfa_gan.GanTrainer(G, D, precision="fp32", inputs_resident=True)
+    seed = int(z[f"step.{name}.seed"])
+    batches = []
+    for i in range(steps):
+        a = torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).cuda()
+        b = torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).cuda()
+        batches.append((tr.pack(a), tr.pack(b)))
+    torch.cuda.synchronize()
+    got = [tr.step_packed(xa, xb).clone() for xa, xb in batches]      # enqueue every step before looking at any result
+    torch.cuda.synchronize()
+    for i, l in enumerate(got):
+        losses = l.cpu().numpy()
+        assert_close(losses[0], z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
+        assert_close(losses[1], z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
+    _check_step_state(z, name, G, D)
