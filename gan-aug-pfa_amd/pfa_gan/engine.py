@@ -354,9 +354,11 @@ class GeneratorEngine(_Engine):
                 ctx.v["aR"][k] = aR
                 break
             aL, aR = ctx.buf(f"e{k}.aL", shape, dt), ctx.buf(f"e{k}.aR", shape, dt)
-            if not train and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w)):
+            if (not train or L.bn is None) and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w)):
                 # eval: the normalisation is a per-channel affine map known up front - apply it in the GEMM epilogue
-                # and emit both readers' operands from there (no raw tensor, no separate pass)
+                # and emit both readers' operands from there (no raw tensor, no separate pass).  The outermost level
+                # has no norm at all (identity map), so it takes this route in training too: its backward reads the
+                # activation sign from aL, never the raw output.
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aL, aR], (B, h, w), self.ws, act=K.ACT_LRELU,
                               affine=self._eval_affine(L, ctx, f"e{k}") + (K.ACT_RELU,))
                 ctx.v["aL"][k], ctx.v["aR"][k] = aL, aR
