@@ -140,7 +140,7 @@ class GanTrainer:
         self.Dn.refresh_shadows(force=True)
 
     # ----------------------------------------------------------------------------------- pieces of a step
-    def _d_phase(self, xa, xb, graph_safe):
+    def _d_phase(self, xa, xb, graph_safe, ready=None):
         G, Dn = self.G, self.Dn
         K.fill_zero(self.losses)
         garena = self.opt_d.flat().grad
@@ -169,8 +169,10 @@ class GanTrainer:
         # later than the side stream may already have added to it) and its gradient arena is zeroed on the side stream.
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
-        if self.inputs_resident and self._d_free_recorded and not graph_safe:
+        if (self.inputs_resident or ready is not None) and self._d_free_recorded and not graph_safe:
             self.side.wait_event(self._ev_d_free)
+            if ready is not None:
+                self.side.wait_event(ready)
         else:
             self.side.wait_stream(main)
         K.fill_zero(garena)
@@ -251,11 +253,15 @@ class GanTrainer:
         """NCHW float32 batch (what batch["image1"].to(DEVICE) is, train_gan.py:53-54) -> engine layout."""
         return K.pack_nhwc(x, self.dtype)
 
-    def step_packed(self, xa, xb):
-        """One G+D step on already packed NHWC inputs.  Returns the device tensor [loss_d, loss_g]."""
+    def step_packed(self, xa, xb, ready=None):
+        """One G+D step on already packed NHWC inputs.  Returns the device tensor [loss_d, loss_g].
+        ready: optional torch.cuda.Event recorded (on whatever stream produced xa / xb) once they are complete; the
+        step's streams wait for it, and D(real) may then start before the previous step's tail has finished."""
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)
         if self.use_graph:
             return self._step_graph(xa, xb)
-        self._d_phase(xa, xb, False)
+        self._d_phase(xa, xb, False, ready if self.side is not None else None)
         self._allreduce(self.opt_d)
         self._d_update_g_phase(xa, xb, False)
         self._allreduce(self.opt_g)
@@ -410,10 +416,36 @@ def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=
         tr = _trainer_for(gen, disc, opt_g, opt_d, process_group=process_group)
         tr.lambda_l1 = float(lambda_l1)
         tr.epoch_losses(reset=True)
+        # Input pipeline: the NEXT batch is copied to the device and packed to NHWC on a stream of its own while the
+        # current step runs; the step waits for the batch's event only (PCIe time overlaps compute).
+        in_stream = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream()
+
+        def stage(batch):
+            in_stream.wait_stream(main)         # (allocator safety: buffers released on main are reusable here)
+            with torch.cuda.stream(in_stream):
+                a = batch["image1"].to(device, non_blocking=True)
+                b = batch["image2"].to(device, non_blocking=True)
+                xa, xb = tr.pack(a), tr.pack(b)
+                ev = torch.cuda.Event()
+                ev.record(in_stream)
+            for t in (xa, xb):                  # used on the trainer's streams: keep the blocks out of reuse until then
+                t.record_stream(main)
+                for st in (tr.side, tr.side2):
+                    if st is not None:
+                        t.record_stream(st)
+            return xa, xb, ev
+
+        staged = None
         for batch in loader:
             if batch is None:
                 continue
-            tr.step(batch["image1"].to(device, non_blocking=True), batch["image2"].to(device, non_blocking=True))
+            nxt = stage(batch)
+            if staged is not None:
+                tr.step_packed(*staged)
+            staged = nxt
+        if staged is not None:
+            tr.step_packed(*staged)
         return tr.epoch_losses()
     bce = torch.nn.BCEWithLogitsLoss()
     l1 = torch.nn.L1Loss()

@@ -468,3 +468,28 @@ def test_fused_step_with_resident_inputs_matches_reference(golden, case):
         assert_close(losses[0], z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
         assert_close(losses[1], z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
     _check_step_state(z, name, G, D)
+
+
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_epoch_loop_with_input_pipeline_matches_reference(golden, case):
+    """pfa_gan.train_gan_one_epoch(G, D, loader, FusedAdam, FusedAdam) - the drop-in for train_gan.py:46-75 - over a
+    loader of CPU batches: the next batch is staged (H2D + pack) on its own stream while a step runs.  One call over all
+    the golden batches: mean losses (train_gan.py:75) and the final state."""
+    name, nd, ngf, ndf, n, h, steps = case
+    z = golden("step")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda().set_precision("fp32")
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda().set_precision("fp32")
+    load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+    load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+    og, od = pfa_gan.FusedAdam(G.parameters()), pfa_gan.FusedAdam(D.parameters())
+    seed = int(z[f"step.{name}.seed"])
+    loader = [dict(image1=torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).pin_memory(),
+                   image2=torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).pin_memory())
+              for i in range(steps)]
+    loader.insert(1, None)          # a batch the collate function dropped (collate_fn_skip_none)
+    ld, lg = pfa_gan.train_gan_one_epoch(G, D, loader, og, od)
+    want_d = np.mean([float(z[f"step.{name}.loss_d{i}"]) for i in range(steps)])
+    want_g = np.mean([float(z[f"step.{name}.loss_g{i}"]) for i in range(steps)])
+    assert_close(ld, want_d, 1e-4, 1e-4, "mean loss_d")
+    assert_close(lg, want_g, 1e-3, 1e-4, "mean loss_g")
+    _check_step_state(z, name, G, D)
