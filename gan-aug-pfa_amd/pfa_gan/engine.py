@@ -119,8 +119,10 @@ class Layer:
         if conv.kernel_size != (4, 4) or conv.padding != (1, 1) or self.stride not in (1, 2):
             raise PfaError(f"{name}: only 4x4 / padding 1 / stride 1|2 convolutions are built")
         if norm is not None and not isinstance(norm, nn.BatchNorm2d):
-            raise NotImplementedError(f"{name}: the HIP engine implements nn.BatchNorm2d (the reference's default, "
-                                      f"train_gan.py:138-139); {type(norm).__name__} runs on the CPU path only")
+            raise NotImplementedError(f"{name}: the fused engine (GanTrainer / FusedAdam) implements nn.BatchNorm2d, the "
+                                      f"reference's default (train_gan.py:138-139); with {type(norm).__name__} call the "
+                                      f"modules themselves - their GPU forward/backward run layer by layer on the HIP "
+                                      f"convolution kernels (pfa_gan.layerwise) under torch.optim")
         self.bn = norm
         self.cout = conv.out_channels
         self.cout_p = K.pad_ch(self.cout, dtype)
@@ -318,8 +320,10 @@ class GeneratorEngine(_Engine):
     def __init__(self, gen, dtype):
         super().__init__(gen, dtype)
         if getattr(gen, "_use_dropout", False):
-            raise NotImplementedError("use_dropout=True is not built into the HIP engine (the reference's "
-                                      "train_gan.py constructs the generator without it)")
+            raise NotImplementedError("use_dropout=True is outside the fused engine (the reference's train_gan.py "
+                                      "constructs the generator without it): call the module itself - its GPU "
+                                      "forward/backward run layer by layer on the HIP convolution kernels "
+                                      "(pfa_gan.layerwise)")
         blocks = gen.blocks()
         self.D = len(blocks)
         self.down, self.up = [], []

@@ -17,11 +17,18 @@ import os
 import torch
 import torch.nn as nn
 
+from . import layerwise
+
 
 def _norm_is_instance(norm_layer):
     """models.py:171-174 / :216-219: convs carry a bias only under InstanceNorm2d."""
     base = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
     return base == nn.InstanceNorm2d
+
+
+def _norm_is_batch(norm_layer):
+    base = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+    return base == nn.BatchNorm2d
 
 
 def default_precision():
@@ -63,10 +70,12 @@ class UnetSkipConnectionBlock(nn.Module):
         bias = _norm_is_instance(norm_layer)
         if input_nc is None:
             input_nc = outer_nc
-        down = nn.Conv2d(input_nc, inner_nc, kernel_size=4, stride=2, padding=1, bias=bias)
+        # (layerwise.Conv2d / ConvTranspose2d are nn.Conv2d / nn.ConvTranspose2d whose CUDA forward runs on libpfa_hip)
+        down = layerwise.Conv2d(input_nc, inner_nc, kernel_size=4, stride=2, padding=1, bias=bias)
         # the transposed conv sees [skip | up] channels except at the bottom of the U
         up_in = inner_nc if innermost else inner_nc * 2
-        up = nn.ConvTranspose2d(up_in, outer_nc, kernel_size=4, stride=2, padding=1, bias=True if outermost else bias)
+        up = layerwise.ConvTranspose2d(up_in, outer_nc, kernel_size=4, stride=2, padding=1,
+                                       bias=True if outermost else bias)
         seq = []
         if not outermost:
             seq.append(nn.LeakyReLU(0.2, True))
@@ -88,9 +97,8 @@ class UnetSkipConnectionBlock(nn.Module):
             dropout=use_dropout and not (outermost or innermost)))
 
     def forward(self, x):
-        if x.is_cuda:
-            raise RuntimeError("UnetSkipConnectionBlock runs on the GPU only as part of UNetGenerator "
-                               "(whole-network HIP engine); call the generator instead")
+        # As a module of its own (and inside a generator with a non-default norm / dropout) a level runs its Sequential:
+        # on the GPU the convolutions are libpfa_hip kernels (pfa_gan.layerwise), the rest is the module graph.
         return self.model(x) if self.outermost else torch.cat([x, self.model(x)], 1)
 
 
@@ -139,9 +147,16 @@ class UNetGenerator(nn.Module):
             self._engines[dtype] = eng
         return eng
 
+    def fused(self):
+        """True for the configuration the fused HIP engine is built for: BatchNorm2d, no dropout (train_gan.py:138)."""
+        return _norm_is_batch(self._norm_layer) and not self._use_dropout
+
     def forward(self, input):
         if not input.is_cuda:
             return self.model(input)
+        if not self.fused():                      # InstanceNorm / dropout variants: layer by layer, HIP convolutions
+            with layerwise.precision(self.precision):
+                return self.model(input)
         from .autograd import generator_apply
         return generator_apply(self, input)
 
@@ -150,8 +165,8 @@ class UNetGenerator(nn.Module):
         """Inference fast path of generate_synthetic_data.py:61-71: G(input) de-normalised (x*0.5+0.5) and converted to
         PNG bytes the way TF.to_pil_image does (mul(255).byte()).  NCHW float batch in [-1,1] -> uint8 [B,H,W,C]; on a
         GPU input the conversion runs on the device (libpfa_hip), on a CPU input it is the same arithmetic in torch."""
-        if not input.is_cuda:
-            return (self.model(input) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).contiguous()
+        if not input.is_cuda or not self.fused():
+            return (self(input) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).contiguous()
         from . import kernels as K
         eng = self.engine()
         eng.refresh_shadows(force=True)
@@ -166,12 +181,12 @@ class NLayerDiscriminator(nn.Module):
         super().__init__()
         bias = _norm_is_instance(norm_layer)
         mults = [min(2 ** n, 8) for n in range(n_layers + 1)]
-        seq = [nn.Conv2d(input_nc, ndf, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(0.2, True)]
+        seq = [layerwise.Conv2d(input_nc, ndf, kernel_size=4, stride=2, padding=1), nn.LeakyReLU(0.2, True)]
         for n in range(1, n_layers + 1):
             stride = 2 if n < n_layers else 1          # the last widening conv keeps the resolution (stride 1)
-            seq += [nn.Conv2d(ndf * mults[n - 1], ndf * mults[n], kernel_size=4, stride=stride, padding=1, bias=bias),
+            seq += [layerwise.Conv2d(ndf * mults[n - 1], ndf * mults[n], kernel_size=4, stride=stride, padding=1, bias=bias),
                     norm_layer(ndf * mults[n]), nn.LeakyReLU(0.2, True)]
-        seq.append(nn.Conv2d(ndf * mults[n_layers], 1, kernel_size=4, stride=1, padding=1))
+        seq.append(layerwise.Conv2d(ndf * mults[n_layers], 1, kernel_size=4, stride=1, padding=1))
         self.model = nn.Sequential(*seq)
         self.input_nc, self.ndf, self.n_layers = input_nc, ndf, n_layers
         self._norm_layer = norm_layer
@@ -193,8 +208,14 @@ class NLayerDiscriminator(nn.Module):
             self._engines[key] = eng
         return eng
 
+    def fused(self):
+        return _norm_is_batch(self._norm_layer)
+
     def forward(self, input):
         if not input.is_cuda:
             return self.model(input)
+        if not self.fused():
+            with layerwise.precision(self.precision):
+                return self.model(input)
         from .autograd import discriminator_apply
         return discriminator_apply(self, input)

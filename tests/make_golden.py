@@ -201,13 +201,15 @@ NET_CASES = [  # name, num_downs, ngf, ndf, N, H
 def _agree(a, b, tol=2e-4):
     """True when two {name: array} results agree to `tol` of each array's max magnitude."""
     for k in a:
+        if np.abs(b[k]).max() < 1e-9 and np.abs(a[k]).max() < 1e-3:
+            continue          # an exactly-zero quantity (a bias in front of an InstanceNorm): fp32 holds round-off only
         scale = max(np.abs(b[k]).max(), 1e-6)
         if np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max() > tol * scale:
             return False
     return True
 
 
-def _pick_seed(run, what):
+def _pick_seed(run, what, tol=2e-4):
     """Smallest data seed whose fp32 reference results agree with the fp64 reference.
 
     A pre-activation within round-off of 0 flips ReLU'/LeakyReLU' between two equally
@@ -216,7 +218,7 @@ def _pick_seed(run, what):
     """
     for seed in range(32):
         r32 = run(torch.float32, seed)
-        if _agree(r32, run(torch.float64, seed)):
+        if _agree(r32, run(torch.float64, seed), tol):
             print(f"  {what}: data seed {seed}")
             return seed, r32
     raise RuntimeError(f"no well-conditioned seed for {what}")
@@ -405,11 +407,61 @@ def gen_siamese(models):
     print("siamese.npz", len(s), "arrays")
 
 
+def gen_variants(models):
+    """The constructor options train_gan.py never selects (models.py:151,168-200,214-219): norm_layer=nn.InstanceNorm2d
+    (biased convolutions, no norm parameters) for both networks - train forward, input / parameter gradients - and
+    use_dropout=True in eval mode (Dropout is the identity there; its training-mode mask has no reference stream to
+    match).  Weights come from oracle/fill.py by state_dict shape, as everywhere."""
+    s = {}
+    n, h, nd, ngf, ndf = 2, 64, 5, 8, 8     # 64x64: the smallest instance-normalised map is 4x4
+
+    def fill_for(module, seed):
+        return fill.fill_state({k: tuple(v.shape) for k, v in module.state_dict().items()}, seed=seed)
+
+    def run_g(dtype, seed):
+        G = models.UNetGenerator(3, 3, num_downs=nd, ngf=ngf, norm_layer=nn.InstanceNorm2d).to(dtype)
+        G.load_state_dict(_to(fill_for(G, 21), dtype))
+        G.train()
+        x = t(fill.uniform("var.g_in.x", (n, 3, h, h), seed=seed)).to(dtype)
+        y = G(x)
+        y.backward(t(fill.uniform("var.g_in.dy", tuple(y.shape), seed=seed)).to(dtype))
+        r = {"g_in.y": y.detach().numpy()}
+        for k, p in G.named_parameters():
+            r[f"g_in.grad.{k}"] = p.grad.numpy()
+        return r
+
+    def run_d(dtype, seed):
+        D = models.NLayerDiscriminator(6, ndf=ndf, norm_layer=nn.InstanceNorm2d).to(dtype)
+        D.load_state_dict(_to(fill_for(D, 22), dtype))
+        D.train()
+        x = t(fill.uniform("var.d_in.x", (n, 6, h, h), seed=seed)).to(dtype).requires_grad_(True)
+        y = D(x)
+        y.backward(t(fill.uniform("var.d_in.dy", tuple(y.shape), seed=seed)).to(dtype))
+        r = {"d_in.y": y.detach().numpy(), "d_in.dx": x.grad.numpy()}
+        for k, p in D.named_parameters():
+            r[f"d_in.grad.{k}"] = p.grad.numpy()
+        return r
+
+    for tag, run in (("g_in", run_g), ("d_in", run_d)):
+        seed, r = _pick_seed(run, f"variants.{tag}", tol=1e-3)     # 16-element instance statistics amplify round-off
+        s[f"var.{tag}.seed"] = np.int64(seed)
+        for k, v in r.items():
+            s[f"var.{k}"] = compact(v) if ".grad." in k else v
+    G = models.UNetGenerator(3, 3, num_downs=6, ngf=ngf, use_dropout=True)
+    G.load_state_dict(_to(fill_for(G, 23), torch.float32))
+    s["var.g_do.keys"] = np.array("\n".join(G.state_dict().keys()))
+    G.eval()
+    with torch.no_grad():
+        s["var.g_do.y_eval"] = G(t(fill.uniform("var.g_do.x", (n, 3, 64, 64)))).numpy()
+    np.savez_compressed(os.path.join(OUT, "variants.npz"), **s)
+    print("variants.npz", len(s), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     models, train_gan = import_reference()
-    which = sys.argv[1:] or ["ops", "nets", "full", "step", "siamese"]      # e.g. `make_golden.py siamese` redoes one file
+    which = sys.argv[1:] or ["ops", "nets", "full", "step", "siamese", "variants"]      # e.g. `make_golden.py siamese` redoes one file
     if "ops" in which:
         gen_ops()
     if "nets" in which:
@@ -420,6 +472,8 @@ def main():
         gen_step(models, train_gan)
     if "siamese" in which:
         gen_siamese(models)
+    if "variants" in which:
+        gen_variants(models)
     with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
         f.write("generated by tests/make_golden.py from /root/reference (Affi-Amine/GAN-AUG-PFA @ 2025-06-14)\n")
         f.write(f"torch {torch.__version__} CPU, numpy {np.__version__}\n")

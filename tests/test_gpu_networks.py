@@ -493,3 +493,73 @@ def test_epoch_loop_with_input_pipeline_matches_reference(golden, case):
     assert_close(ld, want_d, 1e-4, 1e-4, "mean loss_d")
     assert_close(lg, want_g, 1e-3, 1e-4, "mean loss_g")
     _check_step_state(z, name, G, D)
+
+
+# ---------------------------------------------------------------------------- non-default constructor options
+def _fill_for(module, seed):
+    return fill.fill_state({k: tuple(v.shape) for k, v in module.state_dict().items()}, seed=seed)
+
+
+def _variant_grad_ok(got, want, what):
+    """As grad_close; a gradient that is exactly zero in exact arithmetic (a bias in front of an InstanceNorm) only has
+    to be round-off."""
+    want = np.asarray(want, np.float64)
+    if np.abs(want).max() < 1e-4:
+        assert np.abs(np.asarray(got, np.float64)).max() < 1e-3, what
+        return
+    grad_close(got, want, what, rel_l2=5e-3)
+
+
+def test_instance_norm_generator_layerwise_vs_reference(golden):
+    """UNetGenerator(norm_layer=nn.InstanceNorm2d) (models.py:151,171-174) on the GPU: the module graph runs with every
+    convolution on libpfa_hip (pfa_gan.layerwise); train forward and all parameter gradients against the reference."""
+    z = golden("variants")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8, norm_layer=torch.nn.InstanceNorm2d).cuda().set_precision("fp32")
+    assert not G.fused()
+    load(G, _fill_for(G, 21))
+    seed = int(z["var.g_in.seed"])
+    x = torch.from_numpy(fill.uniform("var.g_in.x", (2, 3, 64, 64), seed=seed)).cuda()
+    G.train()
+    before = _lib.launch_count()
+    y = G(x)
+    assert _lib.launch_count() - before >= 2 * 10, "every convolution must be a libpfa_hip launch"
+    assert_close(y.detach().cpu().numpy(), z["var.g_in.y"], ABS, REL, "IN generator forward")
+    y.backward(torch.from_numpy(fill.uniform("var.g_in.dy", tuple(y.shape), seed=seed)).cuda())
+    for k, p in G.named_parameters():
+        _variant_grad_ok(fill.compact(p.grad.cpu().numpy()), z[f"var.g_in.grad.{k}"], f"IN G grad {k}")
+
+
+def test_instance_norm_discriminator_layerwise_vs_reference(golden):
+    z = golden("variants")
+    D = pfa_gan.NLayerDiscriminator(6, ndf=8, norm_layer=torch.nn.InstanceNorm2d).cuda().set_precision("fp32")
+    load(D, _fill_for(D, 22))
+    seed = int(z["var.d_in.seed"])
+    x = torch.from_numpy(fill.uniform("var.d_in.x", (2, 6, 64, 64), seed=seed)).cuda().requires_grad_(True)
+    D.train()
+    y = D(x)
+    assert_close(y.detach().cpu().numpy(), z["var.d_in.y"], ABS, REL, "IN discriminator forward")
+    y.backward(torch.from_numpy(fill.uniform("var.d_in.dy", tuple(y.shape), seed=seed)).cuda())
+    grad_close(x.grad.cpu().numpy(), z["var.d_in.dx"], "IN D input gradient", rel_l2=5e-3)
+    for k, p in D.named_parameters():
+        _variant_grad_ok(fill.compact(p.grad.cpu().numpy()), z[f"var.d_in.grad.{k}"], f"IN D grad {k}")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_dropout_generator_layerwise(golden, precision):
+    """UNetGenerator(use_dropout=True) (models.py:197-198): same keys as the reference; eval mode (Dropout = identity)
+    matches it; train mode runs, drops activations (two forwards differ) and back-propagates finite gradients."""
+    z = golden("variants")
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=6, ngf=8, use_dropout=True).cuda().set_precision(precision)
+    assert list(G.state_dict().keys()) == str(z["var.g_do.keys"]).split("\n") and not G.fused()
+    load(G, _fill_for(G, 23))
+    x = torch.from_numpy(fill.uniform("var.g_do.x", (2, 3, 64, 64))).cuda()
+    G.eval()
+    with torch.no_grad():
+        ye = G(x).cpu().numpy()
+    tol = (ABS, REL) if precision == "fp32" else (3e-2, 3e-2)
+    assert_close(ye, z["var.g_do.y_eval"], *tol, "dropout generator, eval forward")
+    G.train()
+    y1, y2 = G(x), G(x)
+    assert float((y1 - y2).detach().abs().max()) > 1e-3, "training-mode dropout must change the output between calls"
+    y1.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in G.parameters())
