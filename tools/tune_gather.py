@@ -1,5 +1,6 @@
-"""Record every distinct pfa_gather_gemm launch of one fused step (B=16, 256x256, bf16) and time it under
-tile configs {1: 128x128, 6: 256x128 2-stage} x split-K {1,2,4,8,16}.  Prints the best combination per launch."""
+"""Record every distinct pfa_gather_gemm launch of one fused step (B=16, 256x256, bf16) and time it under the tile
+knob {0: automatic, 4: 256x128 for n >= 128} x split-K {1,2,4,8,16}.  Prints the best combination per launch and the
+step totals (automatic choice vs per-launch optimum)."""
 import sys, collections
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import torch
@@ -38,7 +39,7 @@ for key, (cnt, (mode, srcs, w, n, outs, grid, ws, kw)) in calls.items():
     _lib.lib().pfa_set_knob(0, 0)
     t_auto = timeit(lambda: real(mode, srcs, w, n, outs, grid, ws, **kw))
     res = {}
-    for cfg in ((1, 6) if n > 64 else (0,)):
+    for cfg in ((0, 4) if n > 64 else (0,)):
         _lib.lib().pfa_set_knob(0, cfg)
         for sk in (1, 2, 4, 8, 16):
             if sk > 1 and (16 if mode != K.TCONV_S2 else 4) * (ctot // 8) // 8 < 2 * sk: continue
