@@ -7,6 +7,8 @@ tensor produced by the HIP engine.  Checks (each rank):
   * parameters and Adam moments are bit-identical on both ranks after every step (same reduced gradient everywhere);
   * the update equals the one a single process computes from the MEAN of the two ranks' local gradients
     (train_gan.py:55-75 per rank, gradients averaged), recomputed here without a process group.
+PFA_DP_RESIDENT=1: three pre-packed steps enqueued back to back with GanTrainer(inputs_resident=True) - the next step's
+D(real) pass starts under the current step's tail - compared after the last one.
 """
 import os
 import sys
@@ -37,9 +39,11 @@ def main():
     torch.cuda.set_device(0)
     nd, ngf, ndf, n, h = 5, 8, 8, 2, 32
     overlap = os.environ.get("PFA_DP_OVERLAP", "1") == "1"
+    resident = os.environ.get("PFA_DP_RESIDENT", "0") == "1"      # pre-packed batches + GanTrainer(inputs_resident=True)
     # rank r starts from DIFFERENT weights; the broadcast must make rank 0's the job's
     G, D = build(21 + rank, 31 + rank, nd, ngf, ndf)
-    tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=dist.group.WORLD, overlap=overlap)
+    tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=dist.group.WORLD, overlap=overlap,
+                            inputs_resident=resident)
     pfa_gan.broadcast_model(G, dist.group.WORLD)
     pfa_gan.broadcast_model(D, dist.group.WORLD)
     tr.G.refresh_shadows(force=True)
@@ -56,8 +60,15 @@ def main():
         b = torch.from_numpy(fill.uniform(f"dp.b{step}.{r}", (n, 3, h, h))).cuda()
         return a, b
 
-    for step in range(2):
-        tr.step(*data(step, rank))
+    nsteps = 3 if resident else 2
+    packed_mine = [tuple(tr.pack(t) for t in data(st, rank)) for st in range(nsteps)]
+    torch.cuda.synchronize()
+    if resident:                      # enqueue every step before any check: consecutive steps overlap on the device
+        for st in range(nsteps):
+            tr.step_packed(*packed_mine[st])
+    for step in range(nsteps):
+        if not resident:
+            tr.step(*data(step, rank))
         # --- reference: D phase on each rank's data, mean gradient, one Adam step; then the G phase likewise
         packed = [(t.pack(a), t.pack(b)) for t, (a, b) in zip(refs, [data(step, r) for r in range(world)])]
         for t, (xa, xb) in zip(refs, packed):
@@ -72,6 +83,8 @@ def main():
             t.opt_g.flat().grad.copy_(gg)
             t._g_update(False)
         torch.cuda.synchronize()
+        if resident and step < nsteps - 1:
+            continue                  # every step is already enqueued: only the final state can be compared
         for name, mine, ref in (("G", tr.opt_g, refs[rank].opt_g), ("D", tr.opt_d, refs[rank].opt_d)):
             p, q = mine.flat().data, ref.flat().data
             # Adam's first steps move every parameter by ~lr * sign(g): an element whose gradient is at round-off level
