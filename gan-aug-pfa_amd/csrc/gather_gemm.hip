@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         seg_left = (seg_part ? p.spt - p.sp1 : p.sp1) - kc;
     };
     // piece j of a wide stage: activation row pass j (j < AROWS) or weight row pass j - AROWS
+    int stage_ks = 0;                    // K-step being staged (ablation bit 16 only)
     auto stage_wide_piece = [&](int buf, int j) {
         char* abase = smem + buf * STAGE;
         char* wbase = abase + A_BYTES;
@@ -281,7 +282,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             const int i = j;
             const bool ok = (okmask >> i) & 1u;
             const char* gp = ok ? seg_base + a_off[i] : zero;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
+            // ablation bit 16: the activation tile is staged on every 4th K-step only (results are wrong; the traffic
+            // is that of a kernel that keeps an input patch in LDS across taps) - bounds what such a redesign can gain
+            if (!(p.dbg & 16) || (stage_ks & 3) == 0)
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
             a_off[i] += 128u;
         } else if (wave < WWAVES) {
             const int i = j - AROWS;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         stage_wide_next();
     };
     auto stage = [&](int ks, int buf) {
+        stage_ks = ks;
         if (p.dbg & 8) return;
         if (p.wide) stage_wide(buf);
         else stage_narrow(ks, buf);
@@ -422,6 +427,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             const bool more = ks + 1 < ks1;
             if constexpr (CAN_SPREAD) {
                 const bool sp = more && wide_ok;
+                stage_ks = ks + 1;
                 if (more && !wide_ok) stage(ks + 1, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 read_half_raw(fA, buf, 0, 0);
