@@ -412,6 +412,55 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int b = 0; b < FM; ++b) pin(f.af[slot][b]);
         };
+        if constexpr (EARLY == 3) {
+            // Three LDS stages, the DMA queue never drained (cdna guide T3/T4): step i waits, with a COUNTED vmcnt, for
+            // the pieces of stage i only - those of stage i+1 (issued during step i-1) stay in flight across the barrier -
+            // then issues the pieces of stage i+2 between its first-half MFMAs.  Stage (i+2)%3 held step i-1, whose
+            // reads every wave retired before its MFMAs of step i-1, i.e. before this step's barrier.  Wide staging
+            // only (every wave issues exactly NPIECE instructions per stage: the counted wait relies on it); the host
+            // selects this variant for wide launches (launch_gather).
+            static_assert(ALL_AT_ONCE, "ring variant needs both K halves in registers");
+            constexpr int NPIECE = AROWS + WROWS, MF0 = FN * FM;
+            const int nks = ks1 - ks0;
+            if (nks > 0) stage_wide(0);
+            if (nks > 1) stage_wide(1);
+            for (int i = 0; i < nks; ++i) {
+                const int buf = i % 3;
+                if (i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const bool sp = i + 2 < nks;
+                const int nbuf = (i + 2) % 3;
+                __builtin_amdgcn_sched_barrier(0);
+                read_half_raw(fA, buf, 0, 0);
+                read_half_raw(fA, buf, 1, 1);
+                PFA_WAIT_LGKM(FN + FM);
+                pin_half(fA, 0);
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) {
+                        acc[a][b] = Mma<T>::run(fA.wf[0][a], fA.af[0][b], acc[a][b]);
+                        constexpr int dummy = 0; (void)dummy;
+                        const int idx = a * FM + b;
+                        const int lo = (idx * NPIECE) / MF0, hi = ((idx + 1) * NPIECE) / MF0;   // pieces due after this MFMA
+                        if (hi > lo) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (sp) {
+#pragma unroll
+                                for (int j = lo; j < hi; ++j) stage_wide_piece(nbuf, j);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                if (sp) stage_wide_next();
+                __builtin_amdgcn_sched_barrier(0);
+                PFA_WAIT_LGKM(0);
+                pin_half(fA, 1);
+                mfma_half(fA, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         if (ks0 < ks1) stage(ks0, 0);
         // EARLY == 2 (wide staging, both halves in registers): the DMA pieces of the next tile are spread over the
         // MFMAs of the first half instead of being issued in one burst - a wave stalls on each global_load_lds while
@@ -480,6 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }   // EARLY != 3
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -903,6 +953,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 // (two LDS buffers each).  pfa_set_knob(0, v): v = 4 forces shape 3 on launches with n >= 128, anything else is the
 // automatic choice.  pfa_set_knob(2, v): K-loop variant, 0 = default, v = 1..3 selects EARLY = v - 1.
 struct TileCfg { int id, bm, bn; };
+constexpr int RING_MIN_TILES = 64;     // tuned in situ: 1 and 128 are equal, 256 loses a third of the gain (pfa_set_knob(6, n) overrides)
 
 inline TileCfg choose_cfg(const GatherK& k) {
     static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 256, 128}, {4, 256, 64}};
@@ -911,7 +962,15 @@ inline TileCfg choose_cfg(const GatherK& k) {
     // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
-    if (g_knob[0] == 4) return cfgs[3];
+    if (g_knob[0] == 4 || g_knob[0] == 8) return cfgs[3];     // 8: with the 3-stage ring where it applies
+    if (g_knob[0] == 0) {
+        // Default for n >= 128: the 256x128 tile with the 3-stage ring (one 8-wave workgroup owns the CU, the DMA queue
+        // is never drained) wherever the launch still has enough 256-row tiles; +4.6 % pairs/s over 128x128 everywhere.
+        const long long tiles256 = (long long)((k.M + 255) / 256) * ((k.n + 127) / 128) * (k.mode == PFA_TCONV_S2 ? 4 : 1) *
+                                   k.splitk;
+        const int thr = g_knob[6] > 0 ? g_knob[6] : RING_MIN_TILES;
+        if (k.wide && k.kper >= 3 && tiles256 >= thr) return cfgs[3];
+    }
     if (g_knob[0] == 6) return cfgs[1];              // experiment: 128x64 everywhere
     // (128x64 for unsplit launches with one 128x128 workgroup per CU: -14 % on e3/c3 forward in isolation, nothing in
     //  the step - not enabled.)
@@ -958,7 +1017,7 @@ static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.classes = classes;
     k.order = choose_order(k);
     dim3 grid(k.nwg);
-    const size_t lds = 2 * (BM * 128 + BN * 128);
+    const size_t lds = (EARLY == 3 ? 3 : 2) * (BM * 128 + BN * 128);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, EARLY>,
@@ -975,7 +1034,8 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
     // default K-loop per tile shape (tools/layer_bench.py): spreading the DMA pays on the 128x128 tile; the 128x64 tile
     // (16 MFMAs per wave and K-step, three to four workgroups per CU) is 30-40 % faster with the plain reads-first loop
     static const int default_early[] = {2, 0, 1, 1, 1};
-    const int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : default_early[cfg];
+    int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : default_early[cfg];
+    if ((g_knob[0] == 8 || g_knob[0] == 0) && cfg == 3 && g_knob[2] == 0) early = 2;    // 256x128: the 3-stage ring
     switch (cfg * 3 + early) {
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
         case 1: return launch_gather<T, 128, 128, 2, 2, 1>(k, classes, st);
@@ -987,7 +1047,10 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 7: case 8: return launch_gather<T, 256, 16, 4, 1, 1>(k, classes, st);
         case 9: return launch_gather<T, 256, 128, 4, 2, 0>(k, classes, st);
         case 10: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
-        case 11: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
+        case 11:
+            // knob 2 = 3 on the 256x128 tile: the 3-stage ring (wide launches with at least three K-steps per slice)
+            if (k.wide && k.kper >= 3) return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+            return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
         case 12: return launch_gather<T, 256, 64, 4, 1, 0>(k, classes, st);
         default: return launch_gather<T, 256, 64, 4, 1, 1>(k, classes, st);
     }

@@ -76,9 +76,9 @@ def choose_splitk(mode, M, n, ctot, dtype):
     if ksteps < 8:
         return 1
     if blocks >= 192:
-        # exactly one workgroup per CU and a long K loop: two slices give every CU a second, independent workgroup
-        # to overlap with (measured: c4 dgrad 104 -> 84 us, d4 61 -> 54 us; no gain once K is short)
-        return 2 if blocks < 384 and ksteps >= 64 and n % 4 == 0 else 1
+        # fewer than 384 tiles of 128 rows = fewer than 192 of the 256-row ring tile, one per CU at most: two K slices
+        # fill the chip (measured with the ring tile: e3/c3 forward 48 -> 41 us, c4 dgrad 135 -> 87 us, d4 72 -> 53 us)
+        return 2 if blocks < 384 and ksteps >= 32 and n % 4 == 0 else 1
     return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
 
 
