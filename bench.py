@@ -6,7 +6,7 @@ G fwd, 3x D fwd, both backwards, both Adam updates) at 256x256x3, batch 16 per G
 
 One JSON line on rank 0.  `value` = N * batch * K / (max over ranks of the timed K steps), inputs resident in
 HBM (a pool of pre-packed synthetic batches, seed 1234 + rank).  Extra objects:
-  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,128,128,2,2,2>): HIP-event
+  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,256,128,4,2,3>: 256x128 tile, 8 waves, 3-stage LDS ring): HIP-event
                 time of every launch of it over a pass of the same steps, against its algorithmic conv FLOPs
                 (2 * pixels * Cout * taps * Cin_real per launch; SURVEY 8d counts the same MACs)
   cpu_baseline  the numpy oracle's gan_step (oracle/step.py, "port") on the host cores, bounded sample
@@ -67,7 +67,7 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
             splitk = K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, ctot, srcs[0].dtype)
         if n > 64:      # every launch of this instantiation: unique operand + result bytes (what the PMC pass also covers)
             alg_bytes.append(sum(t.numel() * t.element_size() for t in list(srcs) + list(outs)) + w.numel() * w.element_size())
-        dominant = n > 64 and splitk == 1          # -> k_gather_gemm<T,128,128,2,2>, no split-K slab
+        dominant = n > 64 and splitk == 1          # -> k_gather_gemm<T,256,128,4,2,3>, no split-K slab
         if not dominant:
             return real(mode, srcs, w, n, outs, grid, ws, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -98,16 +98,16 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     achieved = flops / (ms * 1e-3) / 1e12
     traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic_gather128.json")
+    tfile = os.path.join(ROOT, "profiles", "r01_traffic_gather_ring.json")
     if precision == "bf16" and xa.shape[0] == 16 and xa.shape[1] == 256 and os.path.exists(tfile):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.py);
         # counters cannot be read from inside the process being measured
         t = json.load(open(tfile))
-        traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather128.json"
+        traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather_ring.json"
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                 traffic=traffic, traffic_source=traffic_src,
                 algorithmic_bytes_per_launch=round(sum(alg_bytes) / max(len(alg_bytes), 1)),
-                kernel=f"k_gather_gemm<{precision},128,128,2,2,2>", launches_per_step=len(rec) // steps,
+                kernel=f"k_gather_gemm<{precision},256,128,4,2,3>", launches_per_step=len(rec) // steps,
                 avg_launch_us=round(1e3 * ms / len(rec), 2), flop_per_launch=round(flops / len(rec)),
                 flop_share_of_step=round(flops / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3))
 

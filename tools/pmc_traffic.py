@@ -5,7 +5,7 @@ a wide coalesced read stream -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import csv, glob, json, sys
 
-KEY = "gather_gemmIDF16bLi128ELi128ELi2ELi2ELi2"          # k_gather_gemm<bf16,128,128,2,2,EARLY=2>
+KEY = "gather_gemmIDF16bLi256ELi128ELi4ELi2ELi3"          # k_gather_gemm<bf16,256,128,4,2,3>: the 3-stage ring
 
 
 def per_launch(d, counter):
@@ -19,7 +19,7 @@ def per_launch(d, counter):
 
 fetch = per_launch(sys.argv[1], "FETCH_SIZE")
 write = per_launch(sys.argv[2], "WRITE_SIZE")
-out = dict(kernel="k_gather_gemm<bf16,128,128,2,2,2>", launches=len(fetch), fetch_kib_avg=sum(fetch) / len(fetch),
+out = dict(kernel="k_gather_gemm<bf16,256,128,4,2,3>", launches=len(fetch), fetch_kib_avg=sum(fetch) / len(fetch),
            write_kib_avg=sum(write) / len(write),
            traffic_bytes_per_launch=(2 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024,
            note="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)",

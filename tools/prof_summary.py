@@ -11,7 +11,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     name = r['Kernel_Name']
     short = None
-    for key, s in (('gather_gemmIDF16bLi128ELi128','gather128'),('gather_gemmIDF16bLi128ELi64','gather64'),('gather_gemmIDF16bLi256ELi16','gather16'),('k_wgradIDF16bLi128','wgrad128'),('k_wgradIDF16bLi16','wgrad16'),('splitk_finish','finish')):
+    for key, s in (('gather_gemmIDF16bLi256ELi128','ring256'),('gather_gemmIDF16bLi128ELi128','gather128'),('gather_gemmIDF16bLi128ELi64','gather64'),('gather_gemmIDF16bLi256ELi16','gather16'),('k_wgradIDF16bLi128','wgrad128'),('k_wgradIDF16bLi16','wgrad16'),('splitk_finish','finish')):
         if key in name: short = s
     if not short: continue
     key = (short, int(r['Grid_Size_X'])//int(r['Workgroup_Size_X']))

@@ -30,7 +30,7 @@ tot, tt = collections.Counter(), collections.Counter()
 print("kernel    blocks      us      MB    GB/s")
 for a, b in zip(fw, ww):
     name = F[a][0]
-    short = ("g128" if "Li128ELi128" in name else "g64" if "Li128ELi64" in name else "g16" if "Li256ELi16" in name else
+    short = ("ring" if "Li256ELi128" in name else "g128" if "Li128ELi128" in name else "g64" if "Li128ELi64" in name else "g16" if "Li256ELi16" in name else
              "wgrad" if "k_wgradI" in name else "scatter" if "scatter" in name else None)
     mb = (2 * F[a][2] + W[b][2]) * 1024 / 1e6
     key = short or name.split("(")[0][-28:]
