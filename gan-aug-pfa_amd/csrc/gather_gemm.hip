@@ -949,7 +949,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
 
 // ---- tile configuration
 // shape 0: 128x128, 4 waves   shape 1: 128x64, 4 waves   shape 2: 256x16, 4 waves   shape 3: 256x128, 8 waves
-// shape 4: 256x64, 4 waves (knob 0 = 5: for 16 < n <= 64)
+// shape 4: 256x64, 8 waves, 3-stage ring where it applies (16 < n <= 64; off by default, knob 7 = 2 turns it on)
 // (two LDS buffers each).  pfa_set_knob(0, v): v = 4 forces shape 3 on launches with n >= 128, anything else is the
 // automatic choice.  pfa_set_knob(2, v): K-loop variant, 0 = default, v = 1..3 selects EARLY = v - 1.
 struct TileCfg { int id, bm, bn; };
@@ -958,7 +958,14 @@ constexpr int RING_MIN_TILES = 64;     // tuned in situ: 1 and 128 are equal, 25
 inline TileCfg choose_cfg(const GatherK& k) {
     static const TileCfg cfgs[] = {{0, 128, 128}, {1, 128, 64}, {2, 256, 16}, {3, 256, 128}, {4, 256, 64}};
     if (k.n <= 16) return cfgs[2];
-    if (k.n <= 64) return g_knob[0] == 5 ? cfgs[4] : cfgs[1];
+    if (k.n <= 64) {
+        // 256x64 with the 3-stage ring (8 waves, 120 KiB) for the wide launches with enough tiles; else 128x64
+        const long long tiles = (long long)((k.M + 255) / 256) * (k.mode == PFA_TCONV_S2 ? 4 : 1) * k.splitk;
+        const bool ring_ok = k.wide && k.kper >= 3 && tiles >= (g_knob[6] > 0 ? g_knob[6] : RING_MIN_TILES);
+        // (measured slower than 128x64 reads-first: d2 forward 75 vs 61 us, -1 % in the step: knob 7 = 2 enables it)
+        if (g_knob[0] == 5 || (g_knob[0] == 0 && ring_ok && g_knob[7] == 2)) return cfgs[4];
+        return cfgs[1];
+    }
     // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
@@ -1051,8 +1058,9 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
             // knob 2 = 3 on the 256x128 tile: the 3-stage ring (wide launches with at least three K-steps per slice)
             if (k.wide && k.kper >= 3) return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
             return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
-        case 12: return launch_gather<T, 256, 64, 4, 1, 0>(k, classes, st);
-        default: return launch_gather<T, 256, 64, 4, 1, 1>(k, classes, st);
+        default:
+            if (k.wide && k.kper >= 3) return launch_gather<T, 256, 64, 4, 2, 3>(k, classes, st);
+            return launch_gather<T, 256, 64, 4, 2, 1>(k, classes, st);
     }
 }
 
