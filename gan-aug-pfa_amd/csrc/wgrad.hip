@@ -37,7 +37,7 @@ struct WgradK {
     int jtot;        // 16 * gp
     int jtiles, itiles, nwg;
     int dbg;         // ablation bits (pfa_set_knob 1): 1 no atomics, 4 no MFMA, 8 no DMA
-    int early;       // K-loop order (pfa_set_knob 4: 1 = reads first, 2 = DMA first; 0 = default)
+    int early;       // K-loop order (pfa_set_knob 4: 1 = reads first, 2 = DMA first, 3 = 256-row ring tile where it applies; 0 = default)
     float* slab;     // optional [msplit][tiles][BI*128] partial tiles (deterministic combine instead of atomics)
     int msplit;
 };
@@ -60,7 +60,8 @@ __device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
 template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
 
 template <typename T, int BI, int WI, int WJ, int EARLY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
+__global__ __launch_bounds__(64 * WI * WJ) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
+    constexpr int NT = 64 * WI * WJ;                 // 256 threads (4 waves) or 512 (8 waves: the 256-row ring tile)
     constexpr int CH = ElemTraits<T>::CH;
     constexpr bool BF = sizeof(T) == 2;
     constexpr int BJ = 128;
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int RCD = DROWB / 16, RCG = GROWB / 16;   // chunks per tile row
     constexpr int D_BYTES = KM * DROWB, G_BYTES = KM * GROWB, STAGE = D_BYTES + G_BYTES;
     constexpr int DSLOTS = KM * RCD, GSLOTS = KM * RCG;
-    constexpr int DIT = (DSLOTS + 255) / 256, GIT = GSLOTS / 256;
-    static_assert(WI * WJ == 4 && GSLOTS % 256 == 0, "tile shape");
+    constexpr int DIT = (DSLOTS + NT - 1) / NT, GIT = GSLOTS / NT;
+    static_assert((NT == 256 || NT == 512) && GSLOTS % NT == 0, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (ic < p.d1p) { d_base = p.dir1 + (size_t)ic * sizeof(T); d_ld = p.d1p; }
         else if (ic < p.dp) { d_base = p.dir2 + (size_t)(ic - p.d1p) * sizeof(T); d_ld = p.d2p; }
     }
-    const bool d_active = (DSLOTS >= 256) || (tid < DSLOTS);
+    const bool d_active = (DSLOTS >= NT) || (tid < DSLOTS);
     // ---- gathered operand: chunk column -> (tap, channel) fixed per thread
     const int g_cs = tid % RCG, g_r0 = tid / RCG;
     const int g_g = g_cs ^ swz(g_r0, RCG);
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     int g_ni[GIT], g_qy[GIT], g_qx[GIT];
 #pragma unroll
     for (int i = 0; i < GIT; ++i) {
-        const int mg = mbeg + i * (256 / RCG) + g_r0;
+        const int mg = mbeg + i * (NT / RCG) + g_r0;
         g_ni[i] = fastdiv(mg, hw, p.magic_hw);
         const int rem = mg - g_ni[i] * hw;
         g_qy[i] = fastdiv(rem, p.wq, p.magic_wq);
@@ -139,19 +140,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (d_active) {
 #pragma unroll
             for (int i = 0; i < DIT; ++i) {
-                const int mg = mstep + i * (256 / RCD) + d_r0;
+                const int mg = mstep + i * (NT / RCD) + d_r0;
                 const bool ok = d_base && mg < mend;
                 const char* gp = ok ? d_base + (size_t)mg * d_ld * sizeof(T) : zero;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(dbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(dbase + (i * NT + wave * 64) * 16), 16, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < GIT; ++i) {
-            const int mg = mstep + i * (256 / RCG) + g_r0;
+            const int mg = mstep + i * (NT / RCG) + g_r0;
             const int y = g_qy[i] * p.stride - 1 + g_ky, x = g_qx[i] * p.stride - 1 + g_kx;
             const bool ok = (g_base != nullptr) & (mg < mend) & ((unsigned)y < (unsigned)p.hg) & ((unsigned)x < (unsigned)p.wg);
             const char* gp = ok ? g_base + ((size_t)(g_ni[i] * p.hg + y) * p.wg + x) * g_ld * sizeof(T) : zero;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(gbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(gbase + (i * NT + wave * 64) * 16), 16, 0, 0);
             // advance by KM pixels: at most one carry per level (step_col < wq, step_row < hq)
             g_qx[i] += p.step_col;
             if (g_qx[i] >= p.wq) { g_qx[i] -= p.wq; ++g_qy[i]; }
@@ -246,12 +247,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
     };
 
+    if constexpr (EARLY == 3) {
+        // Three LDS stages, DMA queue never drained (same scheme as gather_gemm.hip's EARLY == 3): step i waits with a
+        // counted vmcnt for the pieces of stage i, leaves stage i+1's in flight across the barrier and issues stage
+        // i+2's.  Every wave issues exactly DIT + GIT instructions per stage (the address select never skips one).
+        static_assert(BF && DSLOTS >= NT, "ring variant: bf16, every thread stages direct rows");
+        constexpr int NPIECE = DIT + GIT;
+        const int nsteps = (mend - mbeg + KM - 1) / KM;
+        if (nsteps > 0) stage(mbeg, 0);
+        if (nsteps > 1) stage(mbeg + KM, 1);
+        for (int i = 0; i < nsteps; ++i) {
+            const int rb = i % 3;
+            if (i + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (i + 2 < nsteps) stage(mbeg + (i + 2) * KM, (i + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(rb, true);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k32 = 0; k32 < 2; ++k32) {
+#pragma unroll
+                for (int a = 0; a < FI; ++a) pin(af[k32][a]);
+#pragma unroll
+                for (int b = 0; b < FJ; ++b) pin(bfr[k32][b]);
+            }
+            mfma_frags();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     if (mbeg < mend) stage(mbeg, 0);
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += KM) {
         __syncthreads();              // tile `ms` has landed; everyone is done with the other buffer
         if constexpr (BF) {
-            if constexpr (EARLY) {
+            if constexpr (EARLY == 1) {
                 // DMA first: the next tile is in flight under both the transpose reads and the MFMAs
                 if (ms + KM < mend) stage(ms + KM, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -276,17 +306,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         buf ^= 1;
     }
+    }   // EARLY != 3
 
     if (p.dbg & 1) return;
     if (p.slab) {
-        // partial tile in accumulator order: element ((a*FJ+b)*4+r)*256 + tid -> 256-byte coalesced plain stores
+        // partial tile in accumulator order: element ((a*FJ+b)*4+r)*NT + tid -> coalesced plain stores
         float* dst = p.slab + ((size_t)wid * (p.itiles * p.jtiles) + (size_t)it * p.jtiles + jt) * (BI * BJ) + tid;
 #pragma unroll
         for (int a = 0; a < FI; ++a)
 #pragma unroll
             for (int b = 0; b < FJ; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[((a * FJ + b) * 4 + r) * 256] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r) dst[((a * FJ + b) * 4 + r) * NT] = acc[a][b][r];
         return;
     }
     // ---- epilogue: lane holds D[i = .. + 4*kk + r][j = .. + l15]; scatter-add into the master layout
@@ -320,10 +351,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
 constexpr int RED_GROUP = 64;
 template <int BI, int WI, int WJ>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
-    constexpr int BJ = 128, TI = BI / WI, TJ = BJ / WJ, FJ = TJ / 16;
+    constexpr int BJ = 128, TI = BI / WI, TJ = BJ / WJ, FJ = TJ / 16, NT = 64 * WI * WJ;
     const int tile = blockIdx.x / (BI * BJ / 256);
     const int e = (blockIdx.x % (BI * BJ / 256)) * 256 + threadIdx.x;
-    const int tid = e & 255, q = e >> 8, r = q & 3, ab = q >> 2, b = ab % FJ, a = ab / FJ;
+    const int tid = e % NT, q = e / NT, r = q & 3, ab = q >> 2, b = ab % FJ, a = ab / FJ;     // the producer's layout
     const int lane = tid & 63, wave = tid >> 6, wi = wave % WI, wj = wave / WI;
     const int jt = tile % p.jtiles, it = tile / p.jtiles;
     const int ip = it * BI + wi * TI + a * 16 + 4 * (lane >> 4) + r;
@@ -355,7 +386,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
 template <typename T, int BI, int WI, int WJ, int EARLY>
 int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     constexpr int KM = sizeof(T) == 2 ? 64 : 32;
-    constexpr size_t lds = 2 * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
+    constexpr size_t lds = (EARLY == 3 ? 3 : 2) * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
     k.jtiles = (k.jtot + 127) / 128;
     k.itiles = (k.dp + BI - 1) / BI;
     k.nwg = k.jtiles * k.itiles * msplit;
@@ -367,7 +398,7 @@ int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
         attr_done = true;
     }
     k.msplit = msplit;
-    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY>), grid, dim3(256), lds, st, k);
+    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY>), grid, dim3(64 * WI * WJ), lds, st, k);
     PFA_LAUNCHED("k_wgrad");
     if (k.slab) {
         hipLaunchKernelGGL((k_wgrad_reduce<BI, WI, WJ>),
@@ -428,10 +459,16 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     return 0;
 }
 
+// 256-row tile with the 3-stage ring: bf16 layers with at least 256 direct channels and a K loop long enough for a ring
+static bool wgrad_ring(const pfa_wgrad_args* a, const WgradK& k) {
+    // (measured 3 % slower than the 128-row two-stage tile on the step's layers, tools/wgrad_bench.py: off unless knob 4 = 3)
+    return a->dtype == PFA_BF16 && k.dp >= 256 && k.mper >= 3 * 64 && g_knob[4] == 3;
+}
+
 extern "C" size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a) {
     WgradK k; int msplit; bool small_i;
     if (wgrad_setup(a, k, msplit, small_i)) return 0;
-    const int bi = small_i ? 16 : 128;
+    const int bi = small_i ? 16 : (wgrad_ring(a, k) ? 256 : 128);
     return (size_t)msplit * ((k.jtot + 127) / 128) * ((k.dp + bi - 1) / bi) * bi * 128;
 }
 
@@ -440,7 +477,9 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     if (int rc = wgrad_setup(a, k, msplit, small_i)) return rc;
     hipStream_t st = (hipStream_t)s;
 
-    if (a->dtype == PFA_BF16)
+    if (a->dtype == PFA_BF16) {
+        if (!small_i && wgrad_ring(a, k)) return launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st);
         return small_i ? launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st) : launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st);
+    }
     return small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);
 }

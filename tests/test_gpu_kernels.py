@@ -339,6 +339,46 @@ def test_convT_wgrad(case, dtype, ws):
         close(got, want, torch.float32, name)
 
 
+@pytest.mark.parametrize("case", [("conv_co320", "conv", 2, [32], 32, 32, 320, 2), ("convT_ci256_cat", "convT", 2, [128, 128], 16, 16, 24, 2),
+                                  ("conv_s1_co256", "conv", 2, [16], 23, 23, 256, 1)], ids=lambda c: c[0])
+def test_wgrad_ring_tile(case, ws):
+    """pfa_set_knob(4, 3): the 256-row, 8-wave, 3-stage ring variant of the weight-gradient kernel (bf16, >= 256 direct
+    channels; off by default) - a ragged 320-row direct operand, a virtual-concat direct operand and a stride-1 layer,
+    both combine paths."""
+    name, kind, n, cins, h, w, co, stride = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".rw.x", (n, ci, h, w)), dtype)
+    if kind == "conv":
+        ho, wo = (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+        dy = rnd(fill.uniform(name + ".rw.dy", (n, co, ho, wo)), dtype)
+        _, want, _ = ops.conv2d_bwd(x, fill.uniform(name + ".rw.w", (co, ci, 4, 4)), dy, stride, need_dx=False)
+        rows, cols = co, ci
+    else:
+        dy = rnd(fill.uniform(name + ".rw.dy", (n, co, 2 * h, 2 * w)), dtype)
+        _, want, _ = ops.convT2d_bwd(x, fill.uniform(name + ".rw.w", (ci, co, 4, 4)), dy, need_dx=False)
+        rows, cols = ci, co
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    dyt = to_nhwc(dy, dtype)
+    _lib.lib().pfa_set_knob(4, 3)
+    try:
+        assert n * dyt.shape[1] * dyt.shape[2] >= 2 * 3 * 64 or kind == "convT", "each of the two slices needs >= 3 steps"
+        for use_ws in (None, K.FORCE_SLAB):
+            dw = torch.zeros((rows, 16, cols), dtype=torch.float32, device="cuda")
+            if kind == "conv":
+                K.wgrad([dyt], srcs, dw, stride, [co], cins, msplit=2, ws=use_ws)
+            else:
+                K.wgrad(srcs, [dyt], dw, 2, cins, [co], msplit=2, ws=use_ws)
+            torch.cuda.synchronize()
+            got = dw.cpu().numpy().reshape(rows, 4, 4, cols).transpose(0, 3, 1, 2)
+            close(got, want, torch.float32, name)
+    finally:
+        _lib.lib().pfa_set_knob(4, 0)
+
+
 # ---------------------------------------------------------------------------- BatchNorm, losses, Adam
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
 def test_batchnorm_roundtrip(dtype, ws):

@@ -21,7 +21,7 @@ L = [("e1", (128,128,[64]), (256,256,[8]), 2, [64], [3]),
      ("d1", (128,128,[64,64]), (256,256,[8]), 2, [64,64], [3])]
 import os
 from pfa_gan import _lib as _L
-_L.lib().pfa_set_knob(4, int(os.environ.get("WG_LOOP", "0")))     # knob 4: 1 reads first, 2 DMA first
+_L.lib().pfa_set_knob(4, int(os.environ.get("WG_LOOP", "0")))     # knob 4: 1 reads first, 2 DMA first, 3 ring tile
 tot=0
 for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in L:
     d=[T(B,dh,dw,c) for c in dcs]; g=[T(B,gh,gw,c) for c in gcs]
