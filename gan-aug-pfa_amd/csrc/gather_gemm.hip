@@ -412,7 +412,66 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int b = 0; b < FM; ++b) pin(f.af[slot][b]);
         };
-        if constexpr (EARLY == 3) {
+        if constexpr (EARLY == 4) {
+            // The ring of EARLY == 3, software-pipelined at half-step granularity: the barrier sits in the MIDDLE of a
+            // step.  Step i: issue the reads of (i, second half) -> MFMAs of (i, first half), whose fragments were
+            // read during step i-1, with the DMA pieces of stage i+2 between them -> retire every read of stage i,
+            // wait (counted) for stage i+1, barrier -> issue the reads of (i+1, first half) into the other register
+            // set -> MFMAs of (i, second half).  No MFMA ever waits for an LDS read issued right behind a barrier.
+            // Buffer reuse: stage (i+2)%3 held step i-1, whose reads every wave retired before the barrier of step i-1.
+            static_assert(ALL_AT_ONCE, "ring variant needs both K halves in registers");
+            constexpr int NPIECE = AROWS + WROWS, MF0 = FN * FM;
+            const int nks = ks1 - ks0;
+            Frags fB;
+            if (nks > 0) stage_wide(0);
+            if (nks > 1) stage_wide(1);
+            if (nks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (nks > 0) read_half_raw(fA, 0, 0, 0);
+            auto body = [&](int i, Frags& cur, Frags& nxt) {
+                const int buf = i % 3, nbuf = (i + 2) % 3;
+                const bool sp = i + 2 < nks;
+                read_half_raw(cur, buf, 1, 1);
+                PFA_WAIT_LGKM(FN + FM);                      // the first half (issued a half-step ago) is here
+                pin_half(cur, 0);
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) {
+                        acc[a][b] = Mma<T>::run(cur.wf[0][a], cur.af[0][b], acc[a][b]);
+                        const int idx = a * FM + b;
+                        const int lo = (idx * NPIECE) / MF0, hi = ((idx + 1) * NPIECE) / MF0;
+                        if (hi > lo) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (sp) {
+#pragma unroll
+                                for (int j = lo; j < hi; ++j) stage_wide_piece(nbuf, j);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                if (sp) stage_wide_next();
+                __builtin_amdgcn_sched_barrier(0);
+                PFA_WAIT_LGKM(0);                            // every read of stage i has retired
+                pin_half(cur, 1);
+                if (i + 1 < nks) {
+                    if (sp) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    read_half_raw(nxt, (i + 1) % 3, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_half(cur, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int i = 0;
+            for (; i + 1 < nks; i += 2) {
+                body(i, fA, fB);
+                body(i + 1, fB, fA);
+            }
+            if (i < nks) body(i, fA, fB);
+        } else if constexpr (EARLY == 3) {
             // Three LDS stages, the DMA queue never drained (cdna guide T3/T4): step i waits, with a COUNTED vmcnt, for
             // the pieces of stage i only - those of stage i+1 (issued during step i-1) stay in flight across the barrier -
             // then issues the pieces of stage i+2 between its first-half MFMAs.  Stage (i+2)%3 held step i-1, whose
@@ -429,8 +488,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 if (i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                const bool sp = i + 2 < nks;
+                bool sp = i + 2 < nks;
                 const int nbuf = (i + 2) % 3;
+                if (sp && (p.dbg & 32)) {            // ablation bit 32: the whole stage in one burst, before the reads
+                    stage_wide(nbuf);
+                    sp = false;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 read_half_raw(fA, buf, 0, 0);
                 read_half_raw(fA, buf, 1, 1);
@@ -529,7 +592,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        }   // EARLY != 3
+        }   // two-stage variants
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -1024,7 +1087,7 @@ static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.classes = classes;
     k.order = choose_order(k);
     dim3 grid(k.nwg);
-    const size_t lds = (EARLY == 3 ? 3 : 2) * (BM * 128 + BN * 128);
+    const size_t lds = (EARLY >= 3 ? 3 : 2) * (BM * 128 + BN * 128);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, EARLY>,
@@ -1056,7 +1119,9 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 10: return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
         case 11:
             // knob 2 = 3 on the 256x128 tile: the 3-stage ring (wide launches with at least three K-steps per slice)
-            if (k.wide && k.kper >= 3) return launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+            if (k.wide && k.kper >= 3)
+                return g_knob[7] == 4 ? launch_gather<T, 256, 128, 4, 2, 4>(k, classes, st)      // half-step pipelined ring
+                                      : launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
             return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
         default:
             if (k.wide && k.kper >= 3) return launch_gather<T, 256, 64, 4, 2, 3>(k, classes, st);

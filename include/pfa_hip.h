@@ -52,12 +52,13 @@ const char* pfa_last_error_string(void);
 uint64_t pfa_launch_count(void);
 /* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: gather tile (0 = automatic,
  * 4 = 256x128 two-stage / 8 = 256x128 ring where n >= 128, 6 = 128x64 everywhere, 7 = no ring tiles); id 1: in-kernel ablation bits (1 no stores, 2 no statistics, 4 no MFMA, 8 no DMA,
- * 16 activation tile staged on every 4th K-step only - wrong results, for traffic what-ifs);
+ * 16 activation tile staged on every 4th K-step only - wrong results, for traffic what-ifs; 32 ring: a stage's DMA in one burst);
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage
  * ring tile for >= 256 direct channels);
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
- * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64. */
+ * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
+ * ring on the 256x128 tile. */
 int pfa_set_knob(int id, int value);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA

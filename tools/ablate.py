@@ -19,12 +19,12 @@ def timeit(f, reps=20):
     return e0.elapsed_time(e1)*1e3/reps
 for name, mode, (h,w,cs), n, (hq,wq), (ho,wo) in L:
     srcs=[T(B,h,w,c) for c in cs]; wgt=T(n,16,sum(cs)); o=torch.empty((B,ho,wo,n),device='cuda',dtype=dt)
-    for cfg in ((0, 3),):
+    for cfg in ((0, 0),):
         _lib.lib().pfa_set_knob(0, cfg[0]); _lib.lib().pfa_set_knob(2, cfg[1])
         row=[]
-        for dbg in (0, 1, 4, 8, 12, 16, 17):
+        for dbg in (0, 1, 16, 32):
             _lib.lib().pfa_set_knob(1, dbg)
             row.append((dbg, timeit(lambda: K.gather_gemm(mode, srcs, wgt, n, [o], (B,hq,wq), ws))))
         _lib.lib().pfa_set_knob(1, 0)
-        print(f"{name:9s} cfg{cfg}: " + " ".join(f"[{ {0:'full',1:'nostore',4:'dma-only',8:'mfma-only',12:'skeleton',16:'A/4',17:'A/4 nostore'}[d]}: {t:.1f}]" for d,t in row))
+        print(f"{name:9s} cfg{cfg}: " + " ".join(f"[{ {0:'full',1:'nostore',4:'dma-only',8:'mfma-only',12:'skeleton',16:'A/4',17:'A/4 nostore',32:'ring, DMA in one burst'}[d]}: {t:.1f}]" for d,t in row))
 _lib.lib().pfa_set_knob(0, 0); _lib.lib().pfa_set_knob(2, 0)

@@ -33,7 +33,7 @@ L = [
 ]
 def run(cfg):
     tile, loop = cfg
-    _lib.lib().pfa_set_knob(0, tile); _lib.lib().pfa_set_knob(2, loop)
+    _lib.lib().pfa_set_knob(0, tile); _lib.lib().pfa_set_knob(7, loop)      # knob 7 = 4: half-step pipelined ring
     out = []
     for name, mode, (h,w,cs), n, (hq,wq), (ho,wo) in L:
         srcs = [T(B,h,w,c) for c in cs]
@@ -54,7 +54,7 @@ def run(cfg):
         out.append((name, us, flop/us/1e6))
     return out
 # (tile knob, loop knob): tile 0 auto / 4 = 256x128 / 5 = 256x64 for n <= 64; loop 1 reads-first / 2 DMA-first / 3 DMA spread over the MFMAs
-res = {c: run(c) for c in ((0, 0), (7, 0))}      # (7, 0): knob 0 = 7 is not a tile id -> plain 128x128 / 128x64 defaults
+res = {c: run(c) for c in ((7, 0), (0, 0), (0, 4))}      # tile knob 7 = no ring tiles; (0, 4) = pipelined ring
 print(f"{'layer':12s} " + "  ".join(f"cfg{c}: us   TF/s" for c in res))
 for i,(name, *_r) in enumerate(L):
     print(f"{name:12s} " + "  ".join(f"{res[c][i][1]:8.1f} {res[c][i][2]:6.0f}" for c in res))
