@@ -1110,7 +1110,10 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
         case 1: return launch_gather<T, 128, 128, 2, 2, 1>(k, classes, st);
         case 2: return launch_gather<T, 128, 128, 2, 2, 2>(k, classes, st);
-        case 3: return launch_gather<T, 128, 64, 2, 2, 0>(k, classes, st);
+        case 3:
+            // knob 7 = 5: three-stage ring on the 128x64 tile (72 KiB: still two workgroups per CU)
+            if (g_knob[7] == 5 && k.wide && k.kper >= 3) return launch_gather<T, 128, 64, 2, 2, 3>(k, classes, st);
+            return launch_gather<T, 128, 64, 2, 2, 0>(k, classes, st);
         case 4: return launch_gather<T, 128, 64, 2, 2, 1>(k, classes, st);
         case 5: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
         case 6: return launch_gather<T, 256, 16, 4, 1, 0>(k, classes, st);

@@ -58,7 +58,7 @@ uint64_t pfa_launch_count(void);
  * ring tile for >= 256 direct channels);
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
- * ring on the 256x128 tile. */
+ * ring on the 256x128 tile, 5 = ring on the 128x64 tile. */
 int pfa_set_knob(int id, int value);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA
