@@ -18,6 +18,7 @@ from .models import resolve_dtype
 LAMBDA_L1 = 100.0      # train_gan.py:33
 LEARNING_RATE = 1e-4   # train_gan.py:28-29
 BETAS = (0.5, 0.999)   # train_gan.py:30,140-141
+AUTO_GRAPH_PIXELS = 2 * 256 * 256      # use_graph="auto": hipGraph replay at or below this many pixels per batch
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -101,7 +102,11 @@ class GanTrainer:
         """inputs_resident: the caller guarantees that the (packed) batches handed to step_packed() are complete in
         device memory before the call - e.g. a pool of resident batches, or batches produced on a stream the caller
         has synchronised.  The D(real) pass of a step then no longer waits for the previous step's generator update
-        (see _d_phase)."""
+        (see _d_phase).
+        use_graph: False = eager launch on three streams (the measured configuration); True = the step's three segments
+        replayed as captured hipGraphs; "auto" = hipGraph replay on ONE stream when the first batch is tiny (at most
+        AUTO_GRAPH_PIXELS = 2 x 256 x 256 pixels per GPU: the reference's own BATCH_SIZE = 1, train_gan.py:26, where the
+        step is launch-latency bound and the replay is 26 % faster than eager), eager otherwise."""
         self.gen, self.disc = gen, disc
         self.dtype = resolve_dtype(precision)
         nc_a = gen.input_nc
@@ -136,6 +141,7 @@ class GanTrainer:
         self._loss_real = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = None
         self._static = None
+        self._graph_one_stream = False
         self.G.refresh_shadows(force=True)
         self.Dn.refresh_shadows(force=True)
 
@@ -259,8 +265,11 @@ class GanTrainer:
         step's streams wait for it, and D(real) may then start before the previous step's tail has finished."""
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready)
-        if self.use_graph:
-            return self._step_graph(xa, xb)
+        if self.use_graph == "auto":              # decided by the first batch
+            self.use_graph = xa.shape[0] * xa.shape[1] * xa.shape[2] <= AUTO_GRAPH_PIXELS
+            self._graph_one_stream = bool(self.use_graph)
+        if self.use_graph and (self._static is None or self._static[0].shape == xa.shape):
+            return self._step_graph(xa, xb)       # (a batch of another shape, e.g. a ragged last one, runs eagerly)
         self._d_phase(xa, xb, False, ready if self.side is not None else None)
         self._allreduce(self.opt_d)
         self._d_update_g_phase(xa, xb, False)
@@ -275,6 +284,15 @@ class GanTrainer:
     def _step_graph(self, xa, xb):
         """The same three segments captured once as hipGraphs (static shapes and addresses); the gradient
         all-reduces stay ordinary RCCL calls between them."""
+        side = self.side
+        if self._graph_one_stream:
+            self.side = None                      # capture / replay without the stream forks
+        try:
+            return self._step_graph_inner(xa, xb)
+        finally:
+            self.side = side
+
+    def _step_graph_inner(self, xa, xb):
         if self._graphs is None:
             self._static = (torch.empty_like(xa), torch.empty_like(xb))
             sa, sb = self._static
@@ -344,7 +362,8 @@ def _trainer_for(gen, disc, opt_g, opt_d, precision=None, process_group=None):
     tr = getattr(gen, "_pfa_trainer", None)
     if tr is None or tr.disc is not disc or tr.opt_g is not opt_g or tr.opt_d is not opt_d or tr.pg is not process_group \
             or not (tr.G.still_bound() and tr.Dn.still_bound()):
-        tr = GanTrainer(gen, disc, opt_g, opt_d, precision=precision or gen.precision, process_group=process_group)
+        tr = GanTrainer(gen, disc, opt_g, opt_d, precision=precision or gen.precision, process_group=process_group,
+                        use_graph="auto")
         object.__setattr__(gen, "_pfa_trainer", tr)
     return tr
 
