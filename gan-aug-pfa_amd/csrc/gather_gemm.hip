@@ -504,7 +504,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
                     for (int b = 0; b < FM; ++b) {
                         acc[a][b] = Mma<T>::run(fA.wf[0][a], fA.af[0][b], acc[a][b]);
-                        constexpr int dummy = 0; (void)dummy;
                         const int idx = a * FM + b;
                         const int lo = (idx * NPIECE) / MF0, hi = ((idx + 1) * NPIECE) / MF0;   // pieces due after this MFMA
                         if (hi > lo) {
