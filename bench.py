@@ -54,63 +54,49 @@ def parse():
 
 
 def kernel_roofline(trainer, xa, xb, steps, precision):
-    """HIP events (on torch's current stream = the stream every pfa kernel is launched on) around each
-    launch of the dominant implicit-GEMM instantiation, over `steps` eager steps of the same workload."""
-    from pfa_gan import kernels as K
-    real = K.gather_gemm
-    rec = []
-    alg_bytes = []
-
-    def timed(mode, srcs, w, n, outs, grid, ws, **kw):
-        splitk = kw.get("splitk")
-        ctot = sum(s.shape[3] for s in srcs)
-        if splitk is None:
-            splitk = K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, ctot, srcs[0].dtype)
-        if n > 64:      # every launch of this instantiation: unique operand + result bytes (what the PMC pass also covers)
-            alg_bytes.append(sum(t.numel() * t.element_size() for t in list(srcs) + list(outs)) + w.numel() * w.element_size())
-        dominant = n > 64 and splitk == 1          # -> k_gather_gemm<T,256,128,4,2,3>, no split-K slab
-        if not dominant:
-            return real(mode, srcs, w, n, outs, grid, ws, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = real(mode, srcs, w, n, outs, grid, ws, **kw)
-        e1.record()
-        taps = 4 if mode == K.TCONV_S2 else 16
-        classes = 4 if mode == K.TCONV_S2 else 1
-        rows = grid[0] * grid[1] * grid[2] * classes
-        rec.append((e0, e1, 2.0 * rows * n * taps * ctot))
-        return out
-
-    K.gather_gemm = timed
-    import pfa_gan.engine as E
-    E.K.gather_gemm = timed
+    """Live measurement of the dominant kernel: libpfa_hip brackets every implicit-GEMM kernel launch with HIP events on
+    its launch stream (pfa_gather_timing; a split-K call's finish kernel stays outside) over `steps` eager one-stream
+    steps of the same workload; the instantiation with the largest total time is the dominant kernel and ALL its launches
+    count - the same population `rocprofv3 --kernel-trace --stats` averages for that kernel name
+    (profiles/r01_bench_b16_256_bf16_onestream_kernel_stats.csv is the same mode)."""
+    import ctypes
+    from pfa_gan import _lib
+    lib = _lib.lib()
+    was_graph, was_side = trainer.use_graph, trainer.side
+    trainer.use_graph, trainer.side = False, None      # one stream: nothing else shares the GPU with the timed launches
+    lib.pfa_gather_timing(1)
     try:
-        was_graph, was_side = trainer.use_graph, trainer.side
-        trainer.use_graph, trainer.side = False, None      # one stream: nothing else shares the GPU with the timed launches
         for _ in range(steps):
             trainer.step_packed(xa, xb)
         torch.cuda.synchronize()
-        trainer.use_graph, trainer.side = was_graph, was_side
     finally:
-        K.gather_gemm = real
-        E.K.gather_gemm = real
-    ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-    flops = sum(f for _, _, f in rec)
+        lib.pfa_gather_timing(0)
+        trainer.use_graph, trainer.side = was_graph, was_side
+    per = {}
+    ms, name, flop, byts, sk = ctypes.c_float(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    for i in range(lib.pfa_gather_timing_count()):
+        _lib.check(lib.pfa_gather_timing_get(i, ctypes.byref(ms), ctypes.byref(name), ctypes.byref(flop), ctypes.byref(byts),
+                                             ctypes.byref(sk)), "pfa_gather_timing_get")
+        r = per.setdefault(name.value.decode(), [0.0, 0.0, 0.0, 0, 0])
+        r[0] += ms.value; r[1] += flop.value; r[2] += byts.value; r[3] += 1; r[4] += sk.value > 1
+    kernel, (tms, tflop, tbytes, n, nsplit) = max(per.items(), key=lambda kv: kv[1][0])
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
-    achieved = flops / (ms * 1e-3) / 1e12
+    achieved = tflop / (tms * 1e-3) / 1e12
     traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "r01_traffic_gather_ring.json")
     if precision == "bf16" and xa.shape[0] == 16 and xa.shape[1] == 256 and os.path.exists(tfile):
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.py);
         # counters cannot be read from inside the process being measured
         t = json.load(open(tfile))
-        traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather_ring.json"
+        if t.get("kernel") == kernel:
+            traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather_ring.json"
+    total_ms = sum(v[0] for v in per.values())
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                traffic=traffic, traffic_source=traffic_src,
-                algorithmic_bytes_per_launch=round(sum(alg_bytes) / max(len(alg_bytes), 1)),
-                kernel=f"k_gather_gemm<{precision},256,128,4,2,3>", launches_per_step=len(rec) // steps,
-                avg_launch_us=round(1e3 * ms / len(rec), 2), flop_per_launch=round(flops / len(rec)),
-                flop_share_of_step=round(flops / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3))
+                traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(tbytes / n),
+                kernel=kernel, launches_per_step=n // steps, split_k_launches_per_step=nsplit // steps,
+                avg_launch_us=round(1e3 * tms / n, 2), flop_per_launch=round(tflop / n),
+                flop_share_of_step=round(tflop / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3),
+                share_of_implicit_gemm_time=round(tms / total_ms, 3))
 
 
 def cpu_baseline(size, steps):

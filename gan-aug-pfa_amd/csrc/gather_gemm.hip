@@ -18,7 +18,17 @@
 // 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 #include "pfa_common.h"
 
-int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits
+int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static thread_local const char* g_last_gather_name = "";
+
+// Optional per-launch timing (pfa_gather_timing): HIP events recorded on the launch stream right before and right after the
+// implicit-GEMM kernel of a pfa_gather_gemm call (a split-K call's finish kernel is outside the bracket).
+#include <mutex>
+#include <vector>
+struct TimedLaunch { hipEvent_t e0, e1; const char* name; double flop, bytes; int splitk; };
+static std::mutex g_timed_mu;
+static std::vector<TimedLaunch> g_timed;
+static bool g_timing = false;    // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits
 
 namespace {
 
@@ -1094,6 +1104,9 @@ static int launch_gather(GatherK k, int classes, hipStream_t st) {
         attr_done = true;
     }
     hipLaunchKernelGGL((k_gather_gemm<T, BM, BN, WM, WN, EARLY>), grid, dim3(64 * WM * WN), lds, st, k);
+    static char name[64];
+    if (!name[0]) snprintf(name, sizeof(name), "k_gather_gemm<%s,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, WM, WN, EARLY);
+    g_last_gather_name = name;
     PFA_LAUNCHED("k_gather_gemm");
     return 0;
 }
@@ -1129,6 +1142,33 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
             if (k.wide && k.kper >= 3) return launch_gather<T, 256, 64, 4, 2, 3>(k, classes, st);
             return launch_gather<T, 256, 64, 4, 2, 1>(k, classes, st);
     }
+}
+
+extern "C" const char* pfa_last_gather_kernel(void) { return g_last_gather_name; }
+
+extern "C" int pfa_gather_timing(int enable) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    if (enable) {
+        for (auto& t : g_timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
+        g_timed.clear();
+    }
+    g_timing = enable != 0;
+    return 0;
+}
+
+extern "C" int pfa_gather_timing_count(void) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    return (int)g_timed.size();
+}
+
+extern "C" int pfa_gather_timing_get(int i, float* ms, const char** name, double* flop, double* bytes, int* splitk) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    PFA_REQUIRE(i >= 0 && i < (int)g_timed.size() && ms && name && flop && bytes && splitk, "pfa_gather_timing_get: bad arguments");
+    const TimedLaunch& t = g_timed[i];
+    hipError_t e = hipEventElapsedTime(ms, t.e0, t.e1);     // hipErrorNotReady until the launch has completed
+    if (e != hipSuccess) PFA_FAIL((int)e, "pfa_gather_timing_get: %s (synchronise the stream first)", hipGetErrorString(e));
+    *name = t.name; *flop = t.flop; *bytes = t.bytes; *splitk = t.splitk;
+    return 0;
 }
 
 extern "C" int pfa_set_knob(int id, int value) {
@@ -1186,8 +1226,27 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     int rc;
     GatherK kk = k;
     if (k.splitk > 1) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
+    TimedLaunch tl{};
+    const bool timing = g_timing;
+    if (timing) {
+        (void)hipEventCreate(&tl.e0);
+        (void)hipEventCreate(&tl.e1);
+        (void)hipEventRecord(tl.e0, st);
+    }
     rc = a->dtype == PFA_BF16 ? dispatch_gather<bf16_t>(kk, classes, cfg.id, st)
                               : dispatch_gather<float>(kk, classes, cfg.id, st);
+    if (timing) {
+        (void)hipEventRecord(tl.e1, st);
+        const double es = a->dtype == PFA_BF16 ? 2.0 : 4.0, taps = a->mode == PFA_TCONV_S2 ? 4.0 : 16.0;
+        tl.name = g_last_gather_name;
+        tl.splitk = k.splitk;
+        tl.flop = 2.0 * (double)k.M * classes * k.n * taps * k.ctot;
+        // unique operand + result bytes: both sources, the weight rows used, the output rows written
+        tl.bytes = es * ((double)a->nb * a->hs * a->ws * k.ctot + (double)k.n * 16.0 * k.ctot +
+                         (double)k.npix * (a->ld1 + a->ld2));
+        std::lock_guard<std::mutex> lk(g_timed_mu);
+        g_timed.push_back(tl);
+    }
     if (rc) return rc;
     if (k.splitk > 1) {
         int tiles = 0;

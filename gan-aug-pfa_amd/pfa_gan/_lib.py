@@ -62,6 +62,11 @@ PROTOTYPES = {
     "pfa_last_error_string": (c_char_p, []),
     "pfa_launch_count": (c_uint64, []),
     "pfa_set_knob": (c_int, [c_int, c_int]),
+    "pfa_last_gather_kernel": (c_char_p, []),
+    "pfa_gather_timing": (c_int, [c_int]),
+    "pfa_gather_timing_count": (c_int, []),
+    "pfa_gather_timing_get": (c_int, [c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_double), POINTER(c_double),
+                                      POINTER(c_int)]),
     "pfa_gather_stat_tiles": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_gemm": (c_int, [POINTER(GatherArgs), c_void_p]),
     "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,

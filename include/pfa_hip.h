@@ -60,6 +60,17 @@ uint64_t pfa_launch_count(void);
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile. */
 int pfa_set_knob(int id, int value);
+/* Kernel instantiation the calling thread's most recent pfa_gather_gemm launched, e.g. "k_gather_gemm<bf16,256,128,4,2,3>"
+ * (tile rows, tile columns, wave grid, K-loop variant): lets a profiler script attribute a launch to a kernel name. */
+const char* pfa_last_gather_kernel(void);
+/* Per-launch timing for measurements (bench.py's roofline object): while enabled, every pfa_gather_gemm call records one
+ * HIP event on its launch stream right before and one right after its implicit-GEMM kernel (the finish kernel of a
+ * split-K call stays outside).  pfa_gather_timing(1) clears the store and starts, (0) stops; after synchronising the
+ * stream, pfa_gather_timing_get(i, ...) returns launch i's kernel time in ms, its instantiation name, its algorithmic
+ * FLOPs (2 x rows x n x taps x padded channels), its unique operand + result bytes and its K-slice count. */
+int pfa_gather_timing(int enable);
+int pfa_gather_timing_count(void);
+int pfa_gather_timing_get(int i, float* ms, const char** name, double* flop, double* bytes, int* splitk);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA
  * out[pix(m)][n] = act( bias[n] + sum_{tap,c} src[pix(m)+tap][c] * w[n][tap][c] )
