@@ -84,6 +84,10 @@ template <> struct Mma<float> {
     }
 };
 
+template <typename T> struct Vec4Of;
+template <> struct Vec4Of<float> { typedef f32x4 type; };
+template <> struct Vec4Of<bf16_t> { typedef bf16x4 type; };
+
 template <typename T> __device__ __forceinline__ void store4(char* p, const float* v);
 template <> __device__ __forceinline__ void store4<float>(char* p, const float* v) {
     f32x4 t = {v[0], v[1], v[2], v[3]};
@@ -663,12 +667,46 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         // This launch computes g = dL/d(act(y)) for the tensor `raw` (y = scale*raw + shift).  Turn it into
         // dy = act1'(y)*g (+ act2'(y)*g2) right here and collect the BatchNorm-backward sums (dy, dy*xhat) per column:
         // the separate elementwise pass over g, raw and dy disappears.
+        // Phase 1: every raw / g2 vector this lane needs, loaded unconditionally (lanes or tiles without work read
+        // element 0) so that all of them are in flight together; written with the loads inside `if (valid)` each one
+        // became a separately branched, serialised load - the fused launches were 2x slower than un-fused ones.
+        typedef typename Vec4Of<T>::type vec4_t;
+        vec4_t xr[FN][FM], gr[FN][FM];
+        const bool has_g2 = p.fuse_g2 != nullptr;
+        const int fld = p.fuse_out == 1 ? p.ld1 : p.ld2;
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
             const bool mine = p.fuse_out == 1 ? nbase < p.n1 : nbase >= p.n1;
             const int col = p.fuse_out == 1 ? nbase : nbase - p.n1;
-            const int ld = p.fuse_out == 1 ? p.ld1 : p.ld2;
+            const bool ok_a = mine && col < fld;
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const size_t e = (ok_a && mval[b]) ? opix[b] * fld + col : 0;
+                xr[a][b] = *(const vec4_t*)(p.fuse_raw + e * sizeof(T));
+            }
+        }
+        if (has_g2) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+                const bool mine = p.fuse_out == 1 ? nbase < p.n1 : nbase >= p.n1;
+                const int col = p.fuse_out == 1 ? nbase : nbase - p.n1;
+                const bool ok_a = mine && col < fld;
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const size_t e = (ok_a && mval[b]) ? opix[b] * fld + col : 0;
+                    gr[a][b] = *(const vec4_t*)(p.fuse_g2 + e * sizeof(T));
+                }
+            }
+        }
+        // Phase 2: the arithmetic
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
+            const bool mine = p.fuse_out == 1 ? nbase < p.n1 : nbase >= p.n1;
+            const int col = p.fuse_out == 1 ? nbase : nbase - p.n1;
+            const int ld = fld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { fs[a][r] = 0.f; fq[a][r] = 0.f; }
             if (!mine || col >= ld) continue;
@@ -700,15 +738,18 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 if (!mval[b]) continue;
-                const size_t e = opix[b] * ld + col;
                 float x[4], g2[4] = {0.f, 0.f, 0.f, 0.f};
-                load4<T>(p.fuse_raw + e * sizeof(T), x);
-                if (p.fuse_g2) load4<T>(p.fuse_g2 + e * sizeof(T), g2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = (float)xr[a][b][r];
+                if (has_g2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g2[r] = (float)gr[a][b][r];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y = x[r] * sc[r] + sh[r];
                     float d = act_grad(y, p.fuse_act1, p.slope) * acc[a][b][r];
-                    if (p.fuse_g2) d += act_grad(y, p.fuse_act2, p.slope) * g2[r];
+                    if (has_g2) d += act_grad(y, p.fuse_act2, p.slope) * g2[r];
                     acc[a][b][r] = d;
                     fs[a][r] += d;
                     fq[a][r] += d * ((x[r] - mu[r]) * is[r]);
@@ -1118,6 +1159,7 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
     static const int default_early[] = {2, 0, 1, 1, 1};
     int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : default_early[cfg];
     if ((g_knob[0] == 8 || g_knob[0] == 0) && cfg == 3 && g_knob[2] == 0) early = 2;    // 256x128: the 3-stage ring
+    // (narrow-staging launches on the 128x128 tile keep the spread loop: reads-first measured 40 % slower there)
     switch (cfg * 3 + early) {
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
         case 1: return launch_gather<T, 128, 128, 2, 2, 1>(k, classes, st);

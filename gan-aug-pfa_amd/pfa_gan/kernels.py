@@ -97,6 +97,10 @@ FUSE_BWD = _os.environ.get("PFA_FUSE_BWD", "1") != "0"     # A/B switch for the 
 def auto_splitk(mode, srcs, n, grid):
     if not FUSE_BWD:
         return 0            # "not 1": callers fall back to the separate backward-reduce pass
+    if sum(s.shape[3] for s in srcs) < 8 * ch_of(srcs[0].dtype):
+        # narrow source (the 3-channel image gradient): the fused epilogue doubles that short launch (104 vs 49 us in the
+        # step, tools/insitu_launches.py) while the separate streaming pass costs ~25 us
+        return 0
     return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(s.shape[3] for s in srcs), srcs[0].dtype)
 
 
