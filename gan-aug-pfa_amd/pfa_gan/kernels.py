@@ -87,7 +87,10 @@ def choose_splitk(mode, M, n, ctot, dtype):
         # fewer than 384 tiles of 128 rows = fewer than 192 of the 256-row ring tile, one per CU at most: two K slices
         # fill the chip (measured with the ring tile: e3/c3 forward 48 -> 41 us, c4 dgrad 135 -> 87 us, d4 72 -> 53 us)
         return 2 if blocks < 384 and ksteps >= 32 and n % 4 == 0 else 1
-    return max(1, min(ksteps // 4, math.ceil(512 / blocks), 32))
+    # enough slices for ~512 workgroups, at most 16 and a power of two: even slices (c5: 9 uneven slices 31 us, 8 slices
+    # 24 us) and a bounded slab (the 2x2 / 4x4 layers: 32 slices 32 us, 8-16 slices 26 us; tools/tune_gather.py)
+    want = max(1, min(ksteps // 4, math.ceil(512 / blocks), 16))
+    return 1 << (want.bit_length() - 1)
 
 
 import os as _os
