@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int b = 0; b < FM; ++b) {
                 const size_t e = (ok_a && mval[b]) ? opix[b] * fld + col : 0;
-                xr[a][b] = *(const vec4_t*)(p.fuse_raw + e * sizeof(T));
+                xr[a][b] = *(const vec4_t*)(p.fuse_raw + ((p.dbg & 64) ? 0 : e) * sizeof(T));    // ablation bit 64: no traffic
             }
         }
         if (has_g2) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
                 for (int b = 0; b < FM; ++b) {
                     const size_t e = (ok_a && mval[b]) ? opix[b] * fld + col : 0;
-                    gr[a][b] = *(const vec4_t*)(p.fuse_g2 + e * sizeof(T));
+                    gr[a][b] = *(const vec4_t*)(p.fuse_g2 + ((p.dbg & 64) ? 0 : e) * sizeof(T));
                 }
             }
         }

@@ -11,6 +11,8 @@ xa, xb = tr.pack(a), tr.pack(b)
 for _ in range(4): tr.step_packed(xa, xb)
 torch.cuda.synchronize()
 lib = _lib.lib()
+import os
+lib.pfa_set_knob(1, int(os.environ.get('PFA_DBG', '0')))      # ablation bits (results are wrong when set)
 REPS = 5
 lib.pfa_gather_timing(1)
 for _ in range(REPS): tr.step_packed(xa, xb)
