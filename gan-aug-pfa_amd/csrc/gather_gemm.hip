@@ -122,6 +122,20 @@ template <typename F, int N, int I = 0> struct ReadFrags {
 };
 template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
 
+// Sum of v over the 16 lanes of a DPP row, valid in the row's last lane (lane & 15 == 15): v += row_shr:1,2,4,8 with
+// out-of-row lanes reading zero.  Fixed order, so the result is reproducible.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(sh);
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0x111>(v);      // row_shr:1
+    v = dpp_add<0x112>(v);      // row_shr:2
+    v = dpp_add<0x114>(v);      // row_shr:4
+    v = dpp_add<0x118>(v);      // row_shr:8
+    return v;
+}
+
 // EARLY == 0: K-step = fragment reads -> issue of the next tile's DMA -> MFMAs (the DMA overlaps the MFMAs only).
 // EARLY == 1: K-step = issue of the next tile's DMA -> fragment reads (lds_read16) -> MFMAs: the DMA is in flight
 //             for the whole step (cdna guide T3/T4 "minimum 2-phase": stage before the reads, one barrier per tile).
@@ -796,9 +810,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
                     for (int b = 0; b < FM; ++b) { const float v = acc[a][b][r]; s += v; q += v * v; }
                 }
-#pragma unroll
-                for (int off = 1; off < 16; off <<= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
-                if (lrow == 0) {
+                // sum over the 16 lanes of this DPP row (= the 16 tile rows a lane group holds): four row_shr adds, pure
+                // VALU.  (__shfl_xor lowers to ds_bpermute - an LDS round trip per step, 128 per lane here: ~2 us per launch.)
+                s = row_sum16(s);
+                q = row_sum16(q);
+                if (lrow == 15) {
                     const int nl = wn * TN + a * 16 + 4 * kk + r;
                     red[wm * BN + nl] = s;
                     red[(WM + wm) * BN + nl] = q;
