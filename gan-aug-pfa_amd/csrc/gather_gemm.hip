@@ -302,7 +302,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         seg_left = (seg_part ? p.spt - p.sp1 : p.sp1) - kc;
     };
     // piece j of a wide stage: activation row pass j (j < AROWS) or weight row pass j - AROWS
-    int stage_ks = 0;                    // K-step being staged (ablation bit 16 only)
     auto stage_wide_piece = [&](int buf, int j) {
         char* abase = smem + buf * STAGE;
         char* wbase = abase + A_BYTES;
@@ -310,10 +309,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             const int i = j;
             const bool ok = (okmask >> i) & 1u;
             const char* gp = ok ? seg_base + a_off[i] : zero;
-            // ablation bit 16: the activation tile is staged on every 4th K-step only (results are wrong; the traffic
-            // is that of a kernel that keeps an input patch in LDS across taps) - bounds what such a redesign can gain
-            if (!(p.dbg & 16) || (stage_ks & 3) == 0)
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(abase + (i * NT + wave * 64) * 16), 16, 0, 0);
             a_off[i] += 128u;
         } else if (wave < WWAVES) {
             const int i = j - AROWS;
@@ -336,7 +332,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         stage_wide_next();
     };
     auto stage = [&](int ks, int buf) {
-        stage_ks = ks;
         if (p.dbg & 8) return;
         if (p.wide) stage_wide(buf);
         else stage_narrow(ks, buf);
@@ -499,6 +494,73 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 body(i + 1, fB, fA);
             }
             if (i < nks) body(i, fA, fB);
+        } else if constexpr (EARLY == 5 || EARLY == 6) {
+            // The 3-stage ring with the two waves of every SIMD in OPPOSITE phases (the guide's staggered 8-phase idea):
+            // waves 0-3 (one per SIMD) and waves 4-7 (the second wave of each SIMD) alternate between a read phase
+            // (fragment reads of stage i + the DMA pieces of stage i+2 + the counted wait for stage i+1) and an MFMA
+            // phase, swapping roles at every barrier; the late group runs one barrier behind.  The MFMA pipe of a SIMD
+            // then always has one wave with all its fragments in registers, and LDS reads / DMA issue of the other
+            // wave run under it.  EARLY == 5: one phase pair per K-step (32 MFMAs); 6: one per 32-wide half (16 MFMAs).
+            // Barrier numbering: early group B1(i) = #2i+1, B2(i) = #2i+2; late group #1 extra, B1(i) = #2i+2,
+            // B2(i) = #2i+3 (per phase pair).  RAW: stage i+1 is waited for (own pieces, counted vmcnt) before B1 of the
+            // last phase of step i; a wave reads it after its B2 of that phase, which the other group reaches only
+            // after its own wait.  WAR: stage (i+2)%3 was read in step i-1, reads retired (lgkmcnt(0)) before B1 of its
+            // phase; its DMA is issued after the issuing wave's B2 of that phase, which the other group reaches only
+            // after retiring.
+            static_assert(ALL_AT_ONCE && NT == 512, "staggered ring: eight waves, both K halves in registers");
+            constexpr int NPIECE = AROWS + WROWS;
+            constexpr int NPH = EARLY == 5 ? 1 : 2;
+            const int nks = ks1 - ks0;
+            const bool late = wave >= 4;
+            const bool no_dma = p.dbg & 8, no_mfma = p.dbg & 4, no_read = p.dbg & 128;      // ablations
+            if (nks > 0 && !no_dma) stage_wide(0);
+            if (nks > 1 && !no_dma) stage_wide(1);
+            if (nks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();            // stage 0 is in LDS for everyone
+            if (late) __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < nks; ++i) {
+                const int buf = i % 3, nbuf = (i + 2) % 3;
+                const bool sp = i + 2 < nks && !no_dma;
+#pragma unroll
+                for (int h = 0; h < NPH; ++h) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!no_read || i == 0) {
+                        if constexpr (NPH == 1) {
+                            read_half_raw(fA, buf, 0, 0);
+                            read_half_raw(fA, buf, 1, 1);
+                        } else {
+                            read_half_raw(fA, buf, h, 0);
+                        }
+                    }
+                    if (sp) {
+#pragma unroll
+                        for (int j = h * NPIECE / NPH; j < (h + 1) * NPIECE / NPH; ++j) stage_wide_piece(nbuf, j);
+                    }
+                    if (h == NPH - 1) {
+                        if (sp) {
+                            stage_wide_next();
+                            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    PFA_WAIT_LGKM(0);
+                    pin_half(fA, 0);
+                    if constexpr (NPH == 1) pin_half(fA, 1);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_s_setprio(1);
+                    if (!no_mfma) {
+                        mfma_half(fA, 0);
+                        if constexpr (NPH == 1) mfma_half(fA, 1);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if (!late) __builtin_amdgcn_s_barrier();
         } else if constexpr (EARLY == 3) {
             // Three LDS stages, the DMA queue never drained (cdna guide T3/T4): step i waits, with a COUNTED vmcnt, for
             // the pieces of stage i only - those of stage i+1 (issued during step i-1) stay in flight across the barrier -
@@ -509,14 +571,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             static_assert(ALL_AT_ONCE, "ring variant needs both K halves in registers");
             constexpr int NPIECE = AROWS + WROWS, MF0 = FN * FM;
             const int nks = ks1 - ks0;
-            if (nks > 0) stage_wide(0);
-            if (nks > 1) stage_wide(1);
+            const bool no_dma = p.dbg & 8;
+            if (nks > 0 && !no_dma) stage_wide(0);
+            if (nks > 1 && !no_dma) stage_wide(1);
             for (int i = 0; i < nks; ++i) {
                 const int buf = i % 3;
                 if (i + 1 < nks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                bool sp = i + 2 < nks;
+                bool sp = i + 2 < nks && !no_dma;
                 const int nbuf = (i + 2) % 3;
                 if (sp && (p.dbg & 32)) {            // ablation bit 32: the whole stage in one burst, before the reads
                     stage_wide(nbuf);
@@ -566,7 +629,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
             const bool more = ks + 1 < ks1;
             if constexpr (CAN_SPREAD) {
                 const bool sp = more && wide_ok;
-                stage_ks = ks + 1;
                 if (more && !wide_ok) stage(ks + 1, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 read_half_raw(fA, buf, 0, 0);
@@ -1193,8 +1255,10 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 11:
             // knob 2 = 3 on the 256x128 tile: the 3-stage ring (wide launches with at least three K-steps per slice)
             if (k.wide && k.kper >= 3)
-                return g_knob[7] == 4 ? launch_gather<T, 256, 128, 4, 2, 4>(k, classes, st)      // half-step pipelined ring
-                                      : launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
+                return g_knob[7] == 4   ? launch_gather<T, 256, 128, 4, 2, 4>(k, classes, st)      // half-step pipelined ring
+                       : g_knob[7] == 6 ? launch_gather<T, 256, 128, 4, 2, 5>(k, classes, st)      // staggered ring
+                       : g_knob[7] == 7 ? launch_gather<T, 256, 128, 4, 2, 6>(k, classes, st)      // staggered, half-step phases
+                                        : launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
             return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
         default:
             if (k.wide && k.kper >= 3) return launch_gather<T, 256, 64, 4, 2, 3>(k, classes, st);

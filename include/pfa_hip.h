@@ -52,13 +52,15 @@ const char* pfa_last_error_string(void);
 uint64_t pfa_launch_count(void);
 /* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: gather tile (0 = automatic,
  * 4 = 256x128 two-stage / 8 = 256x128 ring where n >= 128, 6 = 128x64 everywhere, 7 = no ring tiles); id 1: in-kernel ablation bits (1 no stores, 2 no statistics, 4 no MFMA, 8 no DMA,
- * 16 activation tile staged on every 4th K-step only - wrong results, for traffic what-ifs; 32 ring: a stage's DMA in one burst; 64 fused backward epilogue without its raw / g2 traffic);
+ * 32 ring: a stage's DMA in one burst; 64 fused backward epilogue without its raw / g2 traffic; 128 staggered ring: no LDS fragment reads
+ * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set));
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage
  * ring tile for >= 256 direct channels);
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
- * ring on the 256x128 tile, 5 = ring on the 128x64 tile. */
+ * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
+ * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half). */
 int pfa_set_knob(int id, int value);
 /* Kernel instantiation the calling thread's most recent pfa_gather_gemm launched, e.g. "k_gather_gemm<bf16,256,128,4,2,3>"
  * (tile rows, tile columns, wave grid, K-loop variant): lets a profiler script attribute a launch to a kernel name. */

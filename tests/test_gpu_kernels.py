@@ -141,6 +141,62 @@ def test_convT_forward(case, dtype, ws):
           scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
 
 
+RING_LOOPS = [  # knob 7 value, K-loop template parameter of the 256x128 tile
+    (0, 3),     # the default 3-stage ring
+    (4, 4),     # half-step software-pipelined ring
+    (6, 5),     # staggered ring: the two waves of a SIMD in opposite read / MFMA phases
+    (7, 6),     # staggered ring, one phase pair per 32-wide half
+]
+RING_CASES = [  # name, kind, N, cin parts, H, W, Co, stride, splitk
+    ("conv_s2", "conv", 2, [64], 32, 32, 128, 2, 1),
+    ("conv_s2_splitk_ragged", "conv", 3, [128], 18, 22, 200, 2, 2),
+    ("conv_s1", "conv", 2, [64], 17, 19, 128, 1, 1),
+    ("tconv_cat", "tconv", 2, [64, 64], 9, 16, 136, 2, 1),
+]
+
+
+@pytest.mark.parametrize("loop", RING_LOOPS, ids=[f"loop{e}" for _, e in RING_LOOPS])
+@pytest.mark.parametrize("case", RING_CASES, ids=[c[0] for c in RING_CASES])
+def test_ring_loops_of_the_256x128_tile(case, loop, ws):
+    """Every K-loop variant of the dominant kernel (the 8-wave 256x128 tile with three LDS stages) on shapes with ragged
+    rows / columns, K slices and the virtual concat; pfa_set_knob(6, 1) admits the tile on launches this small."""
+    name, kind, n, cins, h, w, co, stride, splitk = case
+    knob7, early = loop
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".x", (n, ci, h, w)), dtype)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    if kind == "conv":
+        wt = rnd(fill.uniform(name + ".w", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        want = ops.conv2d_fwd(x, wt, None, stride)
+        wsh, _ = shadows(wt, dtype, cparts=[(c, K.pad_ch(c, dtype)) for c in cins], want=("same",))
+        mode, grid = (K.CONV_S2 if stride == 2 else K.CONV_S1), (n,) + want.shape[2:]
+    else:
+        wt = rnd(fill.uniform(name + ".w", (ci, co, 4, 4), -0.25, 0.25), dtype)
+        want = ops.convT2d_fwd(x, wt, None)
+        _, wsh = shadows(wt, dtype, want=("tr",))
+        mode, grid = K.TCONV_S2, (n, h, w)
+    out = torch.full((n,) + want.shape[2:] + (K.pad_ch(co, dtype),), 7.0, dtype=dtype, device="cuda")
+    lib = _lib.lib()
+    lib.pfa_set_knob(6, 1)
+    lib.pfa_set_knob(7, knob7)
+    try:
+        st = K.gather_gemm(mode, srcs, wsh, co, [out], grid, ws, stats=True, splitk=splitk)
+        assert lib.pfa_last_gather_kernel().decode() == f"k_gather_gemm<bf16,256,128,4,2,{early}>"
+    finally:
+        lib.pfa_set_knob(6, 0)
+        lib.pfa_set_knob(7, 0)
+    close(from_nhwc(out, co), want, dtype, name)
+    psum, _, nt = st
+    torch.cuda.synchronize()
+    s = psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
+    close(s, want.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
+          scale=np.abs(want).sum(axis=(0, 2, 3)).max())
+
+
 AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs
     ("enc_small", "conv", 2, [8], 16, 16, 8, True),             # narrow staging, 256x16 tile
     ("enc_mid", "conv", 2, [64], 32, 32, 96, True),             # 128x128 tile, ragged columns

@@ -54,7 +54,7 @@ def run(cfg):
         out.append((name, us, flop/us/1e6))
     return out
 # (tile knob, loop knob): tile 0 auto / 4 = 256x128 / 5 = 256x64 for n <= 64; loop 1 reads-first / 2 DMA-first / 3 DMA spread over the MFMAs
-res = {c: run(c) for c in ((0, 0), (0, 5))}      # tile knob 7 = no ring tiles; (0, 4) = pipelined ring
+res = {c: run(c) for c in ((0, 0), (0, 6), (0, 7))}      # knob 7: 4 pipelined ring, 6 / 7 staggered ring (step / half-step phases)
 print(f"{'layer':12s} " + "  ".join(f"cfg{c}: us   TF/s" for c in res))
 for i,(name, *_r) in enumerate(L):
     print(f"{name:12s} " + "  ".join(f"{res[c][i][1]:8.1f} {res[c][i][2]:6.0f}" for c in res))
