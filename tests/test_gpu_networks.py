@@ -564,3 +564,72 @@ def test_dropout_generator_layerwise(golden, precision):
     assert float((y1 - y2).detach().abs().max()) > 1e-3, "training-mode dropout must change the output between calls"
     y1.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in G.parameters())
+
+
+# ---------------------------------------------------------------------------- BASELINE config 2 (B=16, 256x256) by properties
+def _one_step(precision, a, b, gst, dst):
+    G = pfa_gan.UNetGenerator(3, 3).cuda()
+    D = pfa_gan.NLayerDiscriminator(6).cuda()
+    load(G, gst)
+    load(D, dst)
+    tr = pfa_gan.GanTrainer(G, D, precision=precision)
+    losses = tr.step(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    fake = pfa_gan.kernels.unpack_nchw(tr.gctx.v["fake"], 3).cpu().numpy()
+    return losses, fake, {k: v.cpu().numpy() for k, v in G.state_dict().items()}, \
+        {k: v.cpu().numpy() for k, v in D.state_dict().items()}
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config2_step_on_16_copies_equals_step_on_one_pair(precision):
+    """The oracle cannot run B=16 at 256x256 in test time, so the bench configuration is pinned by a size-independent
+    property: a batch made of 16 copies of one pair has the batch statistics, mean losses and mean gradients of that pair
+    alone, hence the same fake image, losses and Adam update as the B=1 step (which test_full_size_step_vs_oracle checks
+    against the oracle) - while running the launch configurations of the bench (256x128 ring tile, K slices, work-list
+    orders, slab reductions of the weight gradients).  Only running_var differs (unbiased factor n/(n-1))."""
+    gst = fill.fill_state(nets.g_state_shapes(), seed=31, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(), seed=32, bn_noise=False)
+    a1 = fill.uniform("copies.a", (1, 3, 256, 256))
+    b1 = fill.uniform("copies.b", (1, 3, 256, 256))
+    l1, f1, g1, d1 = _one_step(precision, a1, b1, gst, dst)
+    l16, f16, g16, d16 = _one_step(precision, np.repeat(a1, 16, 0), np.repeat(b1, 16, 0), gst, dst)
+    rel = 1e-4 if precision == "fp32" else 1e-2
+    assert_close(l16[0], l1[0], 0, rel, "loss_d")
+    assert_close(l16[1], l1[1], 0, rel, "loss_g")
+    assert np.abs(f16 - f16[:1]).max() == 0.0, "the 16 copies must produce one and the same fake image"
+    if precision == "fp32":
+        assert_close(f16[:1], f1, ABS, REL, "fake_B")
+    else:
+        assert np.abs(f16[:1] - f1).mean() < 1e-2
+    lr = 1e-4
+    for got, want, who in ((g16, g1, "G"), (d16, d1, "D")):
+        for k, v in want.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(got[k]) == int(v), k
+            elif k.endswith("running_var"):
+                continue
+            elif k.endswith("running_mean"):
+                assert_close(got[k], v, 1e-4 if precision == "fp32" else 2e-2, 1e-2, f"{who} {k}")
+            else:
+                # Adam's first step moves every parameter by lr * g / (|g| + eps): equal up to the elements whose
+                # gradient is within rounding of zero
+                off = np.mean(np.abs(got[k] - v) > 0.2 * lr)
+                assert off < (0.02 if precision == "fp32" else 0.10), f"{who} {k}: {off:.2%} of the parameters moved differently"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config5_eval_batch_equals_per_tile_forwards(precision):
+    """Eval-mode BatchNorm couples nothing across a batch: a 16-tile generator forward (the inference configuration, large-M
+    launches) must reproduce the single-tile forwards, which the goldens pin."""
+    G = pfa_gan.UNetGenerator(3, 3).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(), seed=33))
+    G.set_precision(precision)
+    G.eval()
+    x = torch.from_numpy(fill.uniform("tiles.x", (16, 3, 256, 256))).cuda()
+    with torch.no_grad():
+        y = G(x)
+        for i in (0, 7, 15):
+            yi = G(x[i:i + 1])
+            if precision == "fp32":
+                assert_close(y[i:i + 1].cpu().numpy(), yi.cpu().numpy(), 1e-5, 1e-4, f"tile {i}")
+            else:
+                assert float((y[i:i + 1] - yi).abs().mean()) < 2e-3, f"tile {i}"
