@@ -38,18 +38,37 @@ inline int grid_chan(int64_t nchunks, int cpr, int cap = 256 * 8) {
 // ------------------------------------------------------------------ BatchNorm statistics
 // Block = 8 channels x 32 tile-lanes: the per-tile partials are summed in parallel (double), then one lane
 // per channel finishes.  Deterministic: fixed tile -> lane assignment and a fixed-order LDS tree.
-constexpr int FIN_CH = 8, FIN_LANES = 32;
+constexpr int FIN_CH = 8, FIN_LANES = 32, FIN_UNROLL = 8;
 __device__ __forceinline__ void tile_sum2(const float* __restrict__ a, const float* __restrict__ b, int ntiles, int c,
                                           int ch, bool valid, double (*sh)[FIN_LANES][FIN_CH], double& ra, double& rb) {
     const int cl = threadIdx.x % FIN_CH, tl = threadIdx.x / FIN_CH;
-    double s = 0.0, q = 0.0;
-    if (valid)
-        for (int t = tl; t < ntiles; t += FIN_LANES) {
-            s += (double)a[(size_t)t * c + ch];
-            q += (double)b[(size_t)t * c + ch];
+    // FIN_UNROLL independent loads per array in flight (the partials were written by other XCDs a moment ago: every load
+    // is a trip past the L2; one dependent load per iteration made a 1024-tile finalize take 20 us) and as many partial
+    // sums, combined in a fixed order
+    double s[FIN_UNROLL], q[FIN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < FIN_UNROLL; ++u) s[u] = q[u] = 0.0;
+    if (valid) {
+        int t = tl;
+        for (; t + (FIN_UNROLL - 1) * FIN_LANES < ntiles; t += FIN_UNROLL * FIN_LANES) {
+            float av[FIN_UNROLL], bv[FIN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FIN_UNROLL; ++u) {
+                av[u] = a[(size_t)(t + u * FIN_LANES) * c + ch];
+                bv[u] = b[(size_t)(t + u * FIN_LANES) * c + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < FIN_UNROLL; ++u) { s[u] += (double)av[u]; q[u] += (double)bv[u]; }
         }
-    sh[0][tl][cl] = s;
-    sh[1][tl][cl] = q;
+#pragma unroll
+        for (int u = 0; u < FIN_UNROLL - 1; ++u)
+            if (t + u * FIN_LANES < ntiles) {
+                s[u] += (double)a[(size_t)(t + u * FIN_LANES) * c + ch];
+                q[u] += (double)b[(size_t)(t + u * FIN_LANES) * c + ch];
+            }
+    }
+    sh[0][tl][cl] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    sh[1][tl][cl] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     __syncthreads();
     for (int off = FIN_LANES / 2; off > 0; off >>= 1) {
         if (tl < off) {
@@ -70,21 +89,30 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
     __shared__ double sh[2][FIN_LANES][FIN_CH];
     const int ch = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += repeats;
+    // the finishing lanes fetch their coefficients BEFORE the reduction: issued after it, each of these loads is a
+    // serial ~1 us round trip on the critical path of the forward pass
+    const bool fin = threadIdx.x < FIN_CH && ch < c;
+    float g32 = 1.f, b32 = 0.f, rm32 = 0.f, rv32 = 0.f;
+    if (fin) {
+        if (gamma) g32 = gamma[ch];
+        if (beta) b32 = beta[ch];
+        if (running_mean) { rm32 = running_mean[ch]; rv32 = running_var[ch]; }
+    }
     double s, q;
     tile_sum2(psum, psq, ntiles, c, ch, ch < c, sh, s, q);
-    if (threadIdx.x >= FIN_CH || ch >= c) return;
+    if (!fin) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double g = gamma ? (double)gamma[ch] : 1.0, b = beta ? (double)beta[ch] : 0.0;
+    const double g = g32, b = b32;
     scale[ch] = (float)(g * invstd);
     shift[ch] = (float)(b - mean * g * invstd);
     if (mean_out) mean_out[ch] = (float)mean;
     if (invstd_out) invstd_out[ch] = (float)invstd;
     if (running_mean && repeats > 0) {
         const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        double rm = running_mean[ch], rv = running_var[ch];
+        double rm = rm32, rv = rv32;
         for (int r = 0; r < repeats; ++r) {
             rm = (1.0 - momentum) * rm + momentum * mean;
             rv = (1.0 - momentum) * rv + momentum * unb;
@@ -222,13 +250,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
                                                          float* coef) {
     __shared__ double sh[2][FIN_LANES][FIN_CH];
     const int ch = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH;
+    const bool fin = threadIdx.x < FIN_CH && ch < c;
+    float g32 = 1.f, is32 = 0.f, mu32 = 0.f, dg32 = 0.f, db32 = 0.f;      // fetched ahead of the reduction (see k_bn_finalize)
+    if (fin) {
+        if (gamma) g32 = gamma[ch];
+        is32 = invstd[ch];
+        mu32 = mean[ch];
+        if (dgamma) dg32 = dgamma[ch];
+        if (dbeta) db32 = dbeta[ch];
+    }
     double sdy, sdyx;
     tile_sum2(part, part + (size_t)ntiles * c, ntiles, c, ch, ch < c, sh, sdy, sdyx);
-    if (threadIdx.x >= FIN_CH || ch >= c) return;
-    if (dgamma) dgamma[ch] += (float)sdyx;       // gradients accumulate into a zeroed arena (zero_grad semantics)
-    if (dbeta) dbeta[ch] += (float)sdy;
-    const double g = gamma ? (double)gamma[ch] : 1.0;
-    const double is = invstd[ch], mu = mean[ch];
+    if (!fin) return;
+    if (dgamma) dgamma[ch] = dg32 + (float)sdyx;       // gradients accumulate into a zeroed arena (zero_grad semantics)
+    if (dbeta) dbeta[ch] = db32 + (float)sdy;
+    const double g = g32;
+    const double is = is32, mu = mu32;
     const double s = g * is;
     // dr = s*(dy - sdy/cnt - xhat*sdyx/cnt),  xhat = (raw-mu)*is
     coef[ch] = (float)s;
@@ -243,8 +280,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* dy, const T* __re
     const int64_t first = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int c0 = (int)(first % cpr) * CH;           // fixed per lane (grid sized as for k_bn_act)
     float ka[CH], kb[CH], kc[CH];
-#pragma unroll
-    for (int e = 0; e < CH; ++e) { ka[e] = coef[c0 + e]; kb[e] = coef[c + c0 + e]; kc[e] = coef[2 * c + c0 + e]; }
+    load_coef<CH>(coef, c0, 0.f, ka);
+    load_coef<CH>(coef + c, c0, 0.f, kb);
+    load_coef<CH>(coef + 2 * c, c0, 0.f, kc);
     for (int64_t idx = first; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
         Chunk<T> d, x, o;
         d.load(dy + idx * CH);
