@@ -1,0 +1,47 @@
+"""Repeat one fused step from the same state many times and report run-to-run deviations (developer tool): a stale or
+racy hand-off shows as an outlier.  PFA_KNOBS selects the code path (3=1: experimental in-kernel reduction of the K slices)."""
+import sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch
+import pfa_gan
+from oracle import fill, nets
+n, h, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+overlap = (sys.argv[5] != "0") if len(sys.argv) > 5 else True
+gst = fill.fill_state(nets.g_state_shapes(), seed=21, bn_noise=False)
+dst = fill.fill_state(nets.d_state_shapes(), seed=22, bn_noise=False)
+a = torch.from_numpy(fill.uniform(f"fs.a.{n}.{h}", (n, 3, h, h))).cuda()
+b = torch.from_numpy(fill.uniform(f"fs.b.{n}.{h}", (n, 3, h, h))).cuda()
+def load(m, st): m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in st.items()}, strict=True)
+G = pfa_gan.UNetGenerator(3, 3).cuda(); D = pfa_gan.NLayerDiscriminator(6).cuda()
+res = []
+snaps = []
+for it in range(reps):
+    load(G, gst); load(D, dst)
+    tr = pfa_gan.GanTrainer(G, D, precision=prec, overlap=overlap)
+    losses = tr.step(a, b).cpu().numpy()
+    fake = pfa_gan.kernels.unpack_nchw(tr.gctx.v["fake"], 3).float()
+    w = G.state_dict()["model.model.1.model.3.model.3.model.1.weight"].float()
+    res.append((losses.copy(), fake.clone(), w.clone()))
+    snap = {}
+    for an, av in vars(tr).items():
+        if hasattr(av, '_t') and hasattr(av, 'v'):
+            for bn_, bt in av._t.items():
+                snap[an + ':' + bn_] = bt.detach().float().clone()
+    snaps.append(snap)
+l0, f0, w0 = res[0]
+for it, (l, f, w) in enumerate(res):
+    dl = np.abs(l - l0).max(); df = float((f - f0).abs().max()); dw = float((w - w0).abs().max())
+    flag = "  <-- outlier" if (dl > 1e-3 or df > 1e-2 or not np.isfinite(l).all()) else ""
+    if flag or it < 3: print(it, l, "dloss %.2e dfake %.2e dw %.2e" % (dl, df, dw), flag)
+print("max dloss", max(np.abs(l - l0).max() for l, _, _ in res), "max dfake", max(float((f - f0).abs().max()) for _, f, _ in res))
+
+names = list(snaps[0].keys())
+diff = {}
+for it in range(1, len(snaps)):
+    for k in names:
+        if k in snaps[it] and snaps[it][k].shape == snaps[0][k].shape and not torch.equal(snaps[it][k], snaps[0][k]):
+            diff[k] = diff.get(k, 0) + 1
+print("buffers that differ from run 0 in at least one run (count of runs):")
+for k in names:
+    if k in diff: print("  ", k, diff[k], tuple(snaps[0][k].shape))
