@@ -994,13 +994,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restrict__ slab, int splitk, int pixels,
                                                            int n, int n1, const float* __restrict__ bias, int act,
                                                            float slope, char* out1, int ld1, char* out2, int ld2,
-                                                           float* psum, float* psq, int cpr, int passes) {
+                                                           float* psum, float* psq, int cpr, int passes,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int act2) {
+    // scale != nullptr: the eval-mode affine epilogue of a K-sliced launch (pfa_gather_args.fuse_out == 3):
+    // y = scale*sum + shift, out1 = act(y) and, when given, out2 = act2(y) over the same columns
     __shared__ float red[2][256][4];
     const int tid = threadIdx.x;
     const int col = tid % cpr, rsub = tid / cpr, rpp = 256 / cpr;
     const int c0 = col * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *(const f32x4*)(bias + c0);
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (scale) { sc4 = *(const f32x4*)(scale + c0); sh4 = *(const f32x4*)(shift + c0); }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     const size_t row0 = (size_t)blockIdx.x * rpp * passes;
     const size_t plane = (size_t)pixels * n;
@@ -1026,6 +1032,18 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
         s += v[ps];
         q += v[ps] * v[ps];
         float o[4];
+        if (scale) {
+            const f32x4 y = v[ps] * sc4 + sh4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = apply_act(y[e], act, slope);
+            store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
+            if (out2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = apply_act(y[e], act2, slope);
+                store4<T>(out2 + (row * ld2 + c0) * sizeof(T), o);
+            }
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = apply_act(v[ps][e], act == PFA_ACT_TANH ? PFA_ACT_NONE : act, slope);
         if (c0 < n1) store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
@@ -1188,7 +1206,10 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of pfa_gather_slab_floats() floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
-    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1), "pfa_gather_gemm: a fused epilogue (fuse_out) cannot be combined with split-K");
+    PFA_REQUIRE(!((a->fuse_out == 1 || a->fuse_out == 2) && k.splitk > 1),
+                "pfa_gather_gemm: a fused backward epilogue (fuse_out 1|2) cannot be combined with split-K");
+    PFA_REQUIRE(!(a->fuse_out == 3 && k.splitk > 1) || (finish_vec_ok(a->n, a->n1, a->ld1, a->act) && k.slab_ld == a->n),
+                "pfa_gather_gemm: the affine epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 and ld1 == n");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
     if (a->mode == PFA_CONV_S1) PFA_REQUIRE(a->hs == a->hq + 1 && a->ws == a->wq + 1, "pfa_gather_gemm: CONV_S1 needs hs=hq+1");
@@ -1397,13 +1418,25 @@ extern "C" int pfa_set_knob(int id, int value) {
     return 0;
 }
 
+static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1, const float* bias, int act,
+                         float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
+                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2);
+
 extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1,
                                  const float* bias, int act, float slope, int dtype, void* out1, int ld1, void* out2,
                                  int ld2, float* psum, float* psq, int* ntiles_stat, pfa_stream s) {
+    return splitk_finish(slab, slab_ld, splitk, pixels, n, n1, bias, act, slope, dtype, out1, ld1, out2, ld2, psum, psq,
+                         ntiles_stat, s, nullptr, nullptr, PFA_ACT_NONE);
+}
+
+static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1, const float* bias, int act,
+                         float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
+                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2) {
     PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0 && slab_ld >= n, "pfa_splitk_finish: bad arguments");
-    PFA_REQUIRE(n1 >= n || out2, "pfa_splitk_finish: out2 missing");
+    PFA_REQUIRE(n1 >= n || out2 || scale, "pfa_splitk_finish: out2 missing");
     PFA_REQUIRE(dtype == PFA_F32 || dtype == PFA_BF16, "pfa_splitk_finish: bad dtype");
     const bool vec = finish_vec_ok(n, n1, ld1, act) && n1 % 4 == 0 && slab_ld == n;
+    PFA_REQUIRE(!scale || vec, "pfa_gather_gemm: the affine epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 and ld1 == n");
     const bool small = !vec && n1 >= n && ld1 <= 16 && !psum;
     const int passes = vec ? finish_passes(n, pixels) : 1;
     const int rpb = vec ? (256 / (n / 4)) * passes : 64;
@@ -1413,10 +1446,10 @@ extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int
     if (vec) {
         if (dtype == PFA_BF16)
             hipLaunchKernelGGL(k_splitk_finish_vec<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2);
         else
             hipLaunchKernelGGL(k_splitk_finish_vec<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2);
     } else if (small) {
         const int grid = (int)(((size_t)pixels * ld1 + 255) / 256);
         if (dtype == PFA_BF16)
@@ -1473,8 +1506,10 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     if (k.splitk > 1 && !inred) {
         int tiles = 0;
         // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n
-        rc = pfa_splitk_finish(k.slab, k.slab_ld, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
-                               k.out2, k.ld2, k.psum, k.psq, &tiles, s);
+        const bool aff = a->fuse_out == 3;
+        rc = splitk_finish(k.slab, k.slab_ld, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
+                           k.out2, k.ld2, k.psum, k.psq, &tiles, s, aff ? a->fuse_scale : nullptr,
+                           aff ? a->fuse_shift : nullptr, a->fuse_act2);
         if (rc) return rc;
         a->ntiles_stat = tiles;
     } else {

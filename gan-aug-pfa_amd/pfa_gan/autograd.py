@@ -16,9 +16,10 @@ class _GeneratorFn(torch.autograd.Function):
     @staticmethod
     def forward(fctx, x, module, needs_grad, *params):
         eng = module.engine()
-        # any optimizer / load_state_dict may have rewritten the masters since the last call; re-emitting the
-        # kernel-side copies costs one pass over the weights, so this path does not try to be clever about it
-        eng.refresh_shadows(force=True)
+        # training: any optimizer may have rewritten the masters since the last call (also through `.data`, which no
+        # counter sees): always re-emit the kernel-side copies, one pass over the weights.  eval (the inference loop of
+        # generate_synthetic_data.py:61-71): only when a version counter moved.
+        eng.refresh_shadows(force=module.training)
         ctx = eng.new_ctx() if needs_grad else eng.scratch_ctx()
         xh = K.pack_nhwc(x, eng.dtype)
         fake = eng.forward(xh, ctx, train=module.training, bn_repeats=1)
@@ -43,7 +44,7 @@ class _DiscriminatorFn(torch.autograd.Function):
     @staticmethod
     def forward(fctx, x, module, needs_grad, *params):
         eng = module.engine()
-        eng.refresh_shadows(force=True)
+        eng.refresh_shadows(force=module.training)
         ctx = eng.new_ctx() if needs_grad else eng.scratch_ctx()
         xh = K.pack_nhwc(x, eng.dtype)
         logits = eng.forward([xh], ctx, train=module.training)

@@ -45,6 +45,7 @@ class FlatParams:
             self.slots[id(p)] = (off, p.numel())
             off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.total = off
+        self.epoch = 0     # bumped by every library kernel that writes the arena behind torch's back (FusedAdam.step)
         self.data = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.params = params
@@ -178,6 +179,7 @@ class _Engine:
         self.ws_cur = self.ws
         self.layers = []
         self._versions = None
+        self.bn_epoch = 0            # bumped whenever a kernel may have written BatchNorm parameters or buffers
         self._scratch = None
         self._table = None
 
@@ -223,10 +225,13 @@ class _Engine:
         return host.to(self.device), n, sb, tb
 
     def refresh_shadows(self, force=False):
-        """Re-emit the kernel-side weight copies when a master parameter changed (torch bumps
-        Tensor._version on every in-place write; the fused trainer forces it after its own Adam)."""
-        versions = tuple(L.w._version for L in self.layers)
+        """Re-emit the kernel-side weight copies when a master parameter changed: torch bumps Tensor._version on every
+        in-place write, the library's own optimizer bumps FlatParams.epoch; the fused trainer forces it after its Adam.
+        (Writes through `param.data` move neither: the train-mode module forward therefore always forces; eval-mode
+        forwards do not - code that edits `.data` of an eval-mode module calls refresh_shadows(force=True) itself.)"""
+        versions = (self.flat.epoch,) + tuple(L.w._version for L in self.layers)
         if force or versions != self._versions:
+            self.bn_epoch += 1          # parameters were written (the fused Adam updates the norm layers' too)
             if self._table is None:
                 self._table = self._shadow_table()
             tab, n, sb, tb = self._table
@@ -236,19 +241,24 @@ class _Engine:
 
     # BatchNorm plumbing ------------------------------------------------------------
     @staticmethod
-    def _affine_ok(mode, srcs, n, grid):
-        """The affine epilogue needs an un-split launch (split-K results are combined by the finish kernel)."""
+    def _affine_ok(mode, srcs, n, grid, ld):
+        """The affine epilogue runs in the GEMM epilogue of an un-split launch, or in the finish pass of a K-sliced one
+        when that takes its vector path (whole 16-byte column chunks that tile 256 lanes, unpadded rows)."""
         if os.environ.get("PFA_AFFINE", "1") == "0":       # A/B switch
             return False
-        return K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(t.shape[3] for t in srcs), srcs[0].dtype) == 1
+        if K.choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(t.shape[3] for t in srcs), srcs[0].dtype) == 1:
+            return True
+        return n % 4 == 0 and n // 4 <= 256 and 256 % (n // 4) == 0 and ld == n
 
     def _eval_affine(self, L, ctx, tag):
         """(scale, shift) of the layer's eval-mode normalisation; the identity for a layer without a norm."""
         if L.bn is None:
             one = ctx.buf(tag + ".one", (L.cout,), torch.float32)
             zero = ctx.buf(tag + ".zero", (L.cout,), torch.float32)
-            one.fill_(1.0)
-            zero.zero_()
+            if ctx.v.get(tag + ".ident") is not one:        # constants: written when the buffers are (re)created only
+                one.fill_(1.0)
+                zero.zero_()
+                ctx.v[tag + ".ident"] = one
             return one, zero
         return self._bn_coeffs(L, ctx, tag, None, 1, False, 1)
 
@@ -261,11 +271,21 @@ class _Engine:
             psum, psq, nt = st
             mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
             track = bn.track_running_stats and bn.running_mean is not None
+            self.bn_epoch += 1          # scale/shift now hold batch statistics; the running statistics move
             K.bn_finalize(psum, psq, nt, c, count, bn.weight, bn.bias, bn.running_mean if track else None,
                           bn.running_var if track else None, bn.num_batches_tracked if track else None,
                           scale, shift, mean, invstd, repeats=repeats if track else 0)
         else:
-            K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, scale, shift)
+            # eval coefficients depend on four tensors that change rarely (load_state_dict, a training step): recompute
+            # them only when one of those was written since - by torch (a tensor's version counter moves on every
+            # in-place write) or by this library's kernels, which write behind torch's back (running statistics in a
+            # train-mode forward, parameters in the fused Adam: both bump self.bn_epoch) - instead of one tiny launch
+            # per layer and forward, 10 % of a B=16 forward
+            key = (self.bn_epoch, scale.data_ptr()) + tuple((t.data_ptr(), t._version) if t is not None else None
+                                              for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+            if ctx.v.get(tag + ".evalkey") != key:
+                K.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, scale, shift)
+                ctx.v[tag + ".evalkey"] = key
         return scale, shift
 
     def _bn_backward(self, L, ctx, tag, raw, count, garena, g1, act1, g2=None, act2=K.ACT_NONE, param_grads=True):
@@ -358,7 +378,7 @@ class GeneratorEngine(_Engine):
                 ctx.v["aR"][k] = aR
                 break
             aL, aR = ctx.buf(f"e{k}.aL", shape, dt), ctx.buf(f"e{k}.aR", shape, dt)
-            if (not train or L.bn is None) and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w)):
+            if (not train or L.bn is None) and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w), L.cout_p):
                 # eval: the normalisation is a per-channel affine map known up front - apply it in the GEMM epilogue
                 # and emit both readers' operands from there (no raw tensor, no separate pass).  The outermost level
                 # has no norm at all (identity map), so it takes this route in training too: its backward reads the
@@ -382,7 +402,7 @@ class GeneratorEngine(_Engine):
             L = self.up[k]
             h, w = H >> (k + 1), W >> (k + 1)
             srcs = [ctx.v["aR"][k]] if k == D - 1 else [ctx.v["aR"][k], ctx.v["uR"][k + 1]]
-            if not train and self._affine_ok(K.TCONV_S2, srcs, L.cout, (B, h, w)):
+            if not train and self._affine_ok(K.TCONV_S2, srcs, L.cout, (B, h, w), L.cout_p):
                 uR = ctx.buf(f"u{k}.uR", (B, 2 * h, 2 * w, L.cout_p), dt)
                 K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [uR], (B, h, w), self.ws, act=K.ACT_RELU,
                               affine=self._eval_affine(L, ctx, f"u{k}") + (K.ACT_NONE,))

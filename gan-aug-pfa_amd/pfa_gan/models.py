@@ -169,7 +169,7 @@ class UNetGenerator(nn.Module):
             return (self(input) * 0.5 + 0.5).mul(255).byte().permute(0, 2, 3, 1).contiguous()
         from . import kernels as K
         eng = self.engine()
-        eng.refresh_shadows(force=True)
+        eng.refresh_shadows(force=self.training)
         fake = eng.forward(K.pack_nhwc(input, eng.dtype), eng.scratch_ctx(), train=self.training, bn_repeats=1)
         return K.unpack_u8(fake, eng.out_nc, 0.5, 0.5)
 

@@ -72,6 +72,7 @@ class FusedAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         g2 = self._grad2 if use_grad2 else None
         self.steps += 1
+        flat.epoch += 1          # the arena is written behind torch's version counters
         if graph_safe:      # step count read from device memory so that a captured launch stays valid on replay
             K.adam_tick(self.step_dev)
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0,

@@ -105,7 +105,8 @@ typedef struct pfa_gather_args {
     float* psum;                 /* optional BatchNorm partial sums   [tiles][n]    */
     float* psq;                  /* optional partial sums of squares  [tiles][n]    */
     float* slab;                 /* splitk>1: float32 workspace of pfa_gather_slab_floats() elements */
-    /* fuse_out == 3, eval-mode BatchNorm folded into a forward launch (generate_synthetic_data.py:55, splitk == 1, no
+    /* fuse_out == 3, eval-mode BatchNorm folded into a forward launch (generate_synthetic_data.py:55; K-sliced launches
+     * apply it in their finish pass, which needs n % 4 == 0, n/4 dividing 256 and ld1 == n; no
      * bias, n1 >= n): y = fuse_scale[n]*acc + fuse_shift[n]; out1 = act(y); out2, if not NULL, = fuse_act2(y) over the
      * same columns (the LeakyReLU and ReLU readers of one encoder activation, models.py:204-208). */
     /* Fused activation / BatchNorm backward (input-gradient launches, splitk == 1, no bias/act): the chosen output

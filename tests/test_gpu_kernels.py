@@ -272,11 +272,13 @@ def test_in_kernel_slice_reduction(case, dtype, ws):
         np.testing.assert_allclose(q_a, q_b, rtol=1e-5, atol=1e-4)
 
 
-AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs
-    ("enc_small", "conv", 2, [8], 16, 16, 8, True),             # narrow staging, 256x16 tile
-    ("enc_mid", "conv", 2, [64], 32, 32, 96, True),             # 128x128 tile, ragged columns
-    ("enc_e1", "conv", 2, [3], 32, 32, 64, True),               # 3-channel image layer, 128x64 tile
-    ("dec", "tconv", 2, [64, 64], 8, 8, 48, False),             # transposed conv, virtual concat, one output
+AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs, K slices
+    ("enc_small", "conv", 2, [8], 16, 16, 8, True, 1),             # narrow staging, 256x16 tile
+    ("enc_mid", "conv", 2, [64], 32, 32, 96, True, 1),             # 128x128 tile, ragged columns
+    ("enc_e1", "conv", 2, [3], 32, 32, 64, True, 1),               # 3-channel image layer, 128x64 tile
+    ("dec", "tconv", 2, [64, 64], 8, 8, 48, False, 1),             # transposed conv, virtual concat, one output
+    ("enc_sliced", "conv", 2, [64], 8, 8, 128, True, 4),           # K-sliced: the affine map moves to the finish pass
+    ("dec_sliced", "tconv", 2, [64, 64], 4, 4, 64, False, 3),
 ]
 
 
@@ -285,7 +287,7 @@ AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs
 def test_affine_epilogue(case, dtype, ws):
     """fuse_out = 3: out1 = LeakyReLU/ReLU(scale*conv + shift), out2 = ReLU(scale*conv + shift) - the eval-mode
     BatchNorm of generate_synthetic_data.py:55 applied inside the launch."""
-    name, mode, n, cins, h, w, co, dual = case
+    name, mode, n, cins, h, w, co, dual, slices = case
     ci = sum(cins)
     x = rnd(fill.uniform(name + ".ax", (n, ci, h, w)), dtype)
     scale = fill.uniform(name + ".asc", (co,), 0.5, 1.5)
@@ -311,7 +313,7 @@ def test_affine_epilogue(case, dtype, ws):
     outs = [torch.full((n, ho, wo, cp), 7.0, dtype=dtype, device="cuda") for _ in range(2 if dual else 1)]
     sc, sh = torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda()
     act1 = K.ACT_LRELU if dual else K.ACT_RELU
-    K.gather_gemm(gmode, srcs, wdev, co, outs, grid, ws, act=act1, splitk=1, affine=(sc, sh, K.ACT_RELU))
+    K.gather_gemm(gmode, srcs, wdev, co, outs, grid, ws, act=act1, splitk=slices, affine=(sc, sh, K.ACT_RELU))
     close(from_nhwc(outs[0], co), ops.leaky_relu(y) if dual else ops.relu(y), dtype, name + " out1", scale=np.abs(y).max())
     if dual:
         close(from_nhwc(outs[1], co), ops.relu(y), dtype, name + " out2", scale=np.abs(y).max())

@@ -633,3 +633,64 @@ def test_config5_eval_batch_equals_per_tile_forwards(precision):
                 assert_close(y[i:i + 1].cpu().numpy(), yi.cpu().numpy(), 1e-5, 1e-4, f"tile {i}")
             else:
                 assert float((y[i:i + 1] - yi).abs().mean()) < 2e-3, f"tile {i}"
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_eval_caches_follow_parameter_and_buffer_writes(precision):
+    """Eval-mode forwards reuse the kernel-side weight copies and the folded BatchNorm coefficients until something
+    writes the masters: torch in-place ops (version counters), load_state_dict, the library's own train-mode forward
+    (running statistics) and fused Adam (parameters, written behind torch's back).  After each kind of write the eval
+    output must equal that of a fresh module built from the current state_dict."""
+    def fresh_eval(state, x):
+        m = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda().set_precision(precision)
+        m.load_state_dict(state)
+        m.eval()
+        with torch.no_grad():
+            return m(x)
+
+    torch.manual_seed(5)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda().set_precision(precision)
+    D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda().set_precision(precision)
+    x = torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1
+    b = torch.rand(2, 3, 64, 64, device="cuda") * 2 - 1
+    G.eval()
+    with torch.no_grad():
+        y0 = G(x)
+        launches = _lib.launch_count()
+        y0b = G(x)
+        per_forward = _lib.launch_count() - launches
+        assert torch.equal(y0, y0b)
+        launches = _lib.launch_count()
+        G(x)
+        assert _lib.launch_count() - launches == per_forward
+        # 1. a torch in-place write to a buffer and to a parameter
+        bn = [m for m in G.modules() if isinstance(m, torch.nn.BatchNorm2d)][1]
+        bn.running_mean.add_(0.25)
+        conv = [m for m in G.modules() if isinstance(m, torch.nn.Conv2d)][1]
+        conv.weight.mul_(1.5)
+        y1 = G(x)
+        assert not torch.equal(y1, y0)
+        assert torch.equal(y1, fresh_eval(G.state_dict(), x))
+    # 2. a fused training step (running statistics and parameters written by the library's kernels)
+    G.train()
+    tr = pfa_gan.GanTrainer(G, D, precision=precision)
+    tr.step(x, b)
+    G.eval()
+    with torch.no_grad():
+        y2 = G(x)
+        assert not torch.equal(y2, y1)
+        assert torch.equal(y2, fresh_eval(G.state_dict(), x))
+    # 3. a train-mode module forward (running statistics move) followed by FusedAdam on torch autograd gradients
+    G.train()
+    opt = pfa_gan.FusedAdam(G.parameters(), lr=1e-3)
+    G(x).abs().mean().backward()
+    opt.step()
+    G.eval()
+    with torch.no_grad():
+        y3 = G(x)
+        assert not torch.equal(y3, y2)
+        assert torch.equal(y3, fresh_eval(G.state_dict(), x))
+        # 4. load_state_dict back to an earlier state
+        sd = {k: v.clone() for k, v in G.state_dict().items()}
+        G.load_state_dict(sd)
+        assert torch.equal(G(x), y3)
