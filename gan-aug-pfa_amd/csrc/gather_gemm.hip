@@ -1267,8 +1267,9 @@ inline int fill_params_geometry(const pfa_gather_args* a, GatherK& k, int& class
 // slab + finish pass: launches on the 256x128 tile - one 8-wave workgroup per CU, the configuration the sc1 hand-off is
 // measured for - when the caller passed a ticket array.  EXPERIMENTAL, off unless pfa_set_knob(3, 1): per kernel it
 // matches the finish pass bit for bit (tests/test_gpu_kernels.py, tools/slice_reduce_stress.py: 0 mismatches in 1800
-// launches), but whole training steps showed rare run-to-run outliers with it (tools/step_repeat.py) whose cause is
-// not found, and it buys +0.5 % only - the few reducing workgroups read the partials about as slowly as the finish pass.
+// launches), but inside the networks the last workgroup sometimes reads partials that have not landed (the discriminator's
+// c4 forward after the c2 / c3 launches: garbage in ~10 % of the runs, tools/engine_repeat.py) - cause not found - and it
+// buys +0.5 % only - the few reducing workgroups read the partials about as slowly as the finish pass.
 inline bool reduce_in_kernel(const GatherK& k, const TileCfg& cfg) {
     return g_knob[3] == 1 && k.splitk > 1 && k.tickets != nullptr && cfg.id == 3;
 }
