@@ -39,6 +39,7 @@ struct WgradK {
     int dbg;         // ablation bits (pfa_set_knob 1): 1 no atomics, 4 no MFMA, 8 no DMA
     int early;       // K-loop order (pfa_set_knob 4: 1 = reads first, 2 = DMA first, 3 = 256-row ring tile where it applies; 0 = default)
     float* slab;     // optional [msplit][tiles][BI*128] partial tiles (deterministic combine instead of atomics)
+    int kgroups;     // 1, or 2: K-group pairs (k_wgrad KG)
     int msplit;
 };
 
@@ -59,13 +60,18 @@ __device__ __forceinline__ bf16x4 lds_read_tr(unsigned addr) {
 }
 template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
 
-template <typename T, int BI, int WI, int WJ, int EARLY>
-__global__ __launch_bounds__(64 * WI * WJ) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
-    constexpr int NT = 64 * WI * WJ;                 // 256 threads (4 waves) or 512 (8 waves: the 256-row ring tile)
+// KG == 2 (bf16): two wave groups share one output tile and split every reduction step between them (KM = 128 pixels per
+// step, group g takes rows 64g..64g+63); their accumulators are added through LDS at the end.  Same waves per CU as two
+// independent 4-wave workgroups, half the partial tiles to write and reduce.
+template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1>
+__global__ __launch_bounds__(64 * WI * WJ * KG) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
+    constexpr int NTO = 64 * WI * WJ;                // threads that own the output tile
+    constexpr int NT = NTO * KG;                     // 256 threads (4 waves) or 512 (8 waves: the 256-row ring tile, KG = 2)
     constexpr int CH = ElemTraits<T>::CH;
     constexpr bool BF = sizeof(T) == 2;
     constexpr int BJ = 128;
-    constexpr int KM = BF ? 64 : 32;                 // pixels per reduction step
+    constexpr int KM = (BF ? 64 : 32) * KG;          // pixels per reduction step
+    static_assert(KG == 1 || (KG == 2 && BF && EARLY != 3), "K groups: bf16, two-stage loops");
     constexpr int TI = BI / WI, TJ = BJ / WJ, FI = TI / 16, FJ = TJ / 16;
     constexpr int DROWB = BI * (int)sizeof(T), GROWB = BJ * (int)sizeof(T);
     constexpr int RCD = DROWB / 16, RCG = GROWB / 16;   // chunks per tile row
@@ -77,7 +83,8 @@ __global__ __launch_bounds__(64 * WI * WJ) __attribute__((amdgpu_waves_per_eu(2)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave % WI, wj = wave / WI;
+    const int kg = wave / (WI * WJ), wv = wave % (WI * WJ);      // K group, wave inside the group
+    const int wi = wv % WI, wj = wv / WI;
     // work list: j-tile fastest (neighbours share the direct tile and overlapping gathered pixels), then i-tile,
     // then reduction slice; each XCD takes one contiguous chunk of it
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(64 * WI * WJ) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
                 // 4 pixels x 16 channels block per 16-lane group, delivered channel-major
-                const int m = 32 * k32 + 8 * kk + 4 * e2 + (l15 >> 2);
+                const int m = 64 * kg + 32 * k32 + 8 * kk + 4 * e2 + (l15 >> 2);
 #pragma unroll
                 for (int a = 0; a < FI; ++a) {
                     const int col = wi * TI + a * 16 + 4 * (lane & 3);
@@ -308,16 +315,34 @@ __global__ __launch_bounds__(64 * WI * WJ) __attribute__((amdgpu_waves_per_eu(2)
     }
     }   // EARLY != 3
 
+    if constexpr (KG == 2) {
+        // group 1 hands its accumulators to group 0 through LDS (BI*BJ floats = 64 KiB of the 128 KiB staging area)
+        __syncthreads();
+        f32x4* xch = (f32x4*)smem;
+        const int t = tid & (NTO - 1);
+        if (kg == 1) {
+#pragma unroll
+            for (int a = 0; a < FI; ++a)
+#pragma unroll
+                for (int b = 0; b < FJ; ++b) xch[(a * FJ + b) * NTO + t] = acc[a][b];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int a = 0; a < FI; ++a)
+#pragma unroll
+            for (int b = 0; b < FJ; ++b) acc[a][b] += xch[(a * FJ + b) * NTO + t];
+    }
     if (p.dbg & 1) return;
     if (p.slab) {
-        // partial tile in accumulator order: element ((a*FJ+b)*4+r)*NT + tid -> coalesced plain stores
-        float* dst = p.slab + ((size_t)wid * (p.itiles * p.jtiles) + (size_t)it * p.jtiles + jt) * (BI * BJ) + tid;
+        // partial tile in accumulator order: element ((a*FJ+b)*4+r)*NTO + tid -> coalesced plain stores
+        float* dst = p.slab + ((size_t)wid * (p.itiles * p.jtiles) + (size_t)it * p.jtiles + jt) * (BI * BJ) + (tid & (NTO - 1));
 #pragma unroll
         for (int a = 0; a < FI; ++a)
 #pragma unroll
             for (int b = 0; b < FJ; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[((a * FJ + b) * 4 + r) * NT] = acc[a][b][r];
+                for (int r = 0; r < 4; ++r) dst[((a * FJ + b) * 4 + r) * NTO] = acc[a][b][r];
         return;
     }
     // ---- epilogue: lane holds D[i = .. + 4*kk + r][j = .. + l15]; scatter-add into the master layout
@@ -383,9 +408,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
     else atomicAdd(dst, tot);
 }
 
-template <typename T, int BI, int WI, int WJ, int EARLY>
+template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1>
 int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
-    constexpr int KM = sizeof(T) == 2 ? 64 : 32;
+    constexpr int KM = (sizeof(T) == 2 ? 64 : 32) * KG;
     constexpr size_t lds = (EARLY == 3 ? 3 : 2) * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
     k.jtiles = (k.jtot + 127) / 128;
     k.itiles = (k.dp + BI - 1) / BI;
@@ -393,12 +418,12 @@ int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     dim3 grid(k.nwg);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     k.msplit = msplit;
-    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY>), grid, dim3(64 * WI * WJ), lds, st, k);
+    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY, KG>), grid, dim3(64 * WI * WJ * KG), lds, st, k);
     PFA_LAUNCHED("k_wgrad");
     if (k.slab) {
         hipLaunchKernelGGL((k_wgrad_reduce<BI, WI, WJ>),
@@ -445,17 +470,24 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     k.dbg = g_knob[1];
     k.early = g_knob[4] == 1 ? 0 : g_knob[4] == 2 ? 1 : WGRAD_DEFAULT_EARLY;
     k.jtot = 16 * k.gp;
-    const int km = a->dtype == PFA_BF16 ? 64 : 32;
+    small_i = k.dp <= 16;
+    msplit = a->msplit < 1 ? 1 : a->msplit;
+    // K-group pairs: bf16 launches on the 128-row tile with at least two reduction slices run as half as many 8-wave
+    // workgroups, each reducing two 64-pixel half-steps per step - half the partial tiles to write and reduce
+    // (e3/c3 43 -> 39 us, e4 49 -> 40 us; +2.2 % pairs/s, +2.0 % when pairing from four slices on only).  knob 4 = 5
+    // turns them off, 6 pairs from four slices on; the explicit loop variants (knob 4 = 1..3) keep the 4-wave tile.
+    const int pair_min = g_knob[4] == 6 ? 4 : 2;
+    k.kgroups = ((g_knob[4] == 0 || g_knob[4] == 4 || g_knob[4] == 6) && a->dtype == PFA_BF16 && !small_i && msplit >= pair_min) ? 2 : 1;
+    if (k.kgroups == 2) msplit = (msplit + 1) / 2;
+    const int km = (a->dtype == PFA_BF16 ? 64 : 32) * k.kgroups;
     k.step_img = km / hw;
     k.step_row = (km % hw) / a->wq;
     k.step_col = (km % hw) % a->wq;
-    msplit = a->msplit < 1 ? 1 : a->msplit;
     int steps = (k.M + km - 1) / km;
     if (msplit > steps) msplit = steps;
     int sper = (steps + msplit - 1) / msplit;
     msplit = (steps + sper - 1) / sper;
     k.mper = sper * km;
-    small_i = k.dp <= 16;
     return 0;
 }
 
@@ -479,6 +511,7 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
 
     if (a->dtype == PFA_BF16) {
         if (!small_i && wgrad_ring(a, k)) return launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st);
+        if (k.kgroups == 2) return launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st);
         return small_i ? launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st) : launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st);
     }
     return small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);

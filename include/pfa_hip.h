@@ -55,8 +55,9 @@ uint64_t pfa_launch_count(void);
  * 32 ring: a stage's DMA in one burst; 64 fused backward epilogue without its raw / g2 traffic; 128 staggered ring: no LDS fragment reads
  * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set));
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
- * over the MFMAs); id 4: weight-gradient K-loop (0 = default, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage
- * ring tile for >= 256 direct channels);
+ * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
+ * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
+ * 5 = no K-group pairs, 6 = pairs from four slices on);
  * id 3: 1 = experimental in-kernel reduction of the K slices (pfa_gather_args.tickets); 0 = slab + finish pass;
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined

@@ -422,7 +422,10 @@ def test_convT_dgrad(case, dtype, ws):
 @pytest.mark.parametrize("case", [("s2", 2, [16], 8, 8, 32, 2, None), ("s2_ci3", 2, [3], 16, 16, 16, 2, None),
                                   ("s2_cat33", 2, [3, 3], 16, 16, 64, 2, None), ("s1", 2, [32], 9, 9, 64, 1, None),
                                   ("s1_co1", 2, [64], 7, 6, 1, 1, None), ("s2_msplit", 4, [64], 32, 32, 128, 2, 5),
-                                  ("s2_co136", 1, [16], 8, 8, 136, 2, 1)], ids=lambda c: c[0])
+                                  ("s2_co136", 1, [16], 8, 8, 136, 2, 1),
+                                  # K-group pairs (bf16, >= 2 slices): a single ragged 128-pixel step, and uneven slice pairs
+                                  ("s2_pairs_ragged", 3, [32], 10, 14, 136, 2, 4), ("s1_pairs", 2, [64], 17, 19, 128, 1, 6)],
+                         ids=lambda c: c[0])
 def test_conv_wgrad(case, dtype, ws):
     name, n, cins, h, w, co, stride, msplit = case
     ci = sum(cins)
