@@ -990,13 +990,27 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
 // Fast path: one float4 column chunk per lane (consecutive lanes = consecutive chunks of a row, coalesced),
 // 256/cpr rows per pass, FIN_PASSES passes per block, per-column partial sums reduced through LDS.
 constexpr int FIN_PASSES = 8;
+// Activation / BatchNorm backward of a K-sliced input-gradient launch (pfa_gather_args.fuse_out 1|2), applied by the
+// finish pass to the summed gradient: same arithmetic as the GEMM epilogue's fused block.
+struct FinishFuse {
+    int out;                 // 0 = off, 1 = out1, 2 = out2
+    int act1, act2;
+    int nreal;               // real channels of the fused output (coefficient array length)
+    int stat_col0, stat_n;   // statistics cover the fused output's columns only
+    const char* raw;
+    const char* g2;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+};
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restrict__ slab, int splitk, int pixels,
                                                            int n, int n1, const float* __restrict__ bias, int act,
                                                            float slope, char* out1, int ld1, char* out2, int ld2,
                                                            float* psum, float* psq, int cpr, int passes,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int act2) {
+                                                           int act2, const FinishFuse fz) {
     // scale != nullptr: the eval-mode affine epilogue of a K-sliced launch (pfa_gather_args.fuse_out == 3):
     // y = scale*sum + shift, out1 = act(y) and, when given, out2 = act2(y) over the same columns
     __shared__ float red[2][256][4];
@@ -1007,6 +1021,22 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     if (bias) bv = *(const f32x4*)(bias + c0);
     f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
     if (scale) { sc4 = *(const f32x4*)(scale + c0); sh4 = *(const f32x4*)(shift + c0); }
+    // fused backward: this lane's four columns of the fused output, their coefficients
+    const bool fmine = fz.out && (fz.out == 1 ? c0 < n1 : c0 >= n1);
+    const int fcol = fz.out == 1 ? c0 : c0 - n1;
+    const int fld = fz.out == 1 ? ld1 : ld2;
+    f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, is4 = {1.f, 1.f, 1.f, 1.f};
+    if (fmine) {
+        const bool whole = fcol + 4 <= fz.nreal;
+        if (fz.scale) {
+            if (whole) { sc4 = *(const f32x4*)(fz.scale + fcol); sh4 = *(const f32x4*)(fz.shift + fcol); }
+            else for (int e = 0; e < 4; ++e) if (fcol + e < fz.nreal) { sc4[e] = fz.scale[fcol + e]; sh4[e] = fz.shift[fcol + e]; }
+        }
+        if (fz.mean) {
+            if (whole) { mu4 = *(const f32x4*)(fz.mean + fcol); is4 = *(const f32x4*)(fz.invstd + fcol); }
+            else for (int e = 0; e < 4; ++e) if (fcol + e < fz.nreal) { mu4[e] = fz.mean[fcol + e]; is4[e] = fz.invstd[fcol + e]; }
+        }
+    }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     const size_t row0 = (size_t)blockIdx.x * rpp * passes;
     const size_t plane = (size_t)pixels * n;
@@ -1029,9 +1059,31 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     for (int ps = 0; ps < FIN_PASSES; ++ps) {
         if (!live[ps]) continue;
         const size_t row = row0 + (size_t)ps * rpp + rsub;
+        float o[4];
+        if (fz.out) {
+            if (fmine) {
+                float x[4], g2[4] = {0.f, 0.f, 0.f, 0.f};
+                load4<T>(fz.raw + (row * fld + fcol) * sizeof(T), x);
+                if (fz.g2) load4<T>(fz.g2 + (row * fld + fcol) * sizeof(T), g2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = x[e] * sc4[e] + sh4[e];
+                    float d = act_grad(y, fz.act1, slope) * v[ps][e];
+                    if (fz.g2) d += act_grad(y, fz.act2, slope) * g2[e];
+                    o[e] = d;
+                    s[e] += d;
+                    q[e] += d * ((x[e] - mu4[e]) * is4[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = v[ps][e];
+            }
+            if (c0 < n1) store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
+            else store4<T>(out2 + (row * ld2 + (c0 - n1)) * sizeof(T), o);
+            continue;
+        }
         s += v[ps];
         q += v[ps] * v[ps];
-        float o[4];
         if (scale) {
             const f32x4 y = v[ps] * sc4 + sh4;
 #pragma unroll
@@ -1064,6 +1116,16 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
         __syncthreads();
     }
     if (tid < cpr) {
+        if (fz.out) {       // rows of stat_n columns: the fused output's only
+            const int sc0 = tid * 4 - fz.stat_col0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sc0 + e >= 0 && sc0 + e < fz.stat_n) {
+                    psum[(size_t)blockIdx.x * fz.stat_n + sc0 + e] = red[0][tid][e];
+                    psq[(size_t)blockIdx.x * fz.stat_n + sc0 + e] = red[1][tid][e];
+                }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             psum[(size_t)blockIdx.x * n + tid * 4 + e] = red[0][tid][e];
@@ -1206,10 +1268,8 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of pfa_gather_slab_floats() floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
-    PFA_REQUIRE(!((a->fuse_out == 1 || a->fuse_out == 2) && k.splitk > 1),
-                "pfa_gather_gemm: a fused backward epilogue (fuse_out 1|2) cannot be combined with split-K");
-    PFA_REQUIRE(!(a->fuse_out == 3 && k.splitk > 1) || (finish_vec_ok(a->n, a->n1, a->ld1, a->act) && k.slab_ld == a->n),
-                "pfa_gather_gemm: the affine epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 and ld1 == n");
+    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1) || (finish_vec_ok(a->n, a->n1, a->ld1, a->act) && k.slab_ld == a->n),
+                "pfa_gather_gemm: a fused epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 (and ld1 == n for one output)");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
     if (a->mode == PFA_CONV_S1) PFA_REQUIRE(a->hs == a->hq + 1 && a->ws == a->wq + 1, "pfa_gather_gemm: CONV_S1 needs hs=hq+1");
@@ -1421,23 +1481,26 @@ extern "C" int pfa_set_knob(int id, int value) {
 
 static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1, const float* bias, int act,
                          float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
-                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2);
+                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2,
+                         const FinishFuse& fz);
 
 extern "C" int pfa_splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1,
                                  const float* bias, int act, float slope, int dtype, void* out1, int ld1, void* out2,
                                  int ld2, float* psum, float* psq, int* ntiles_stat, pfa_stream s) {
     return splitk_finish(slab, slab_ld, splitk, pixels, n, n1, bias, act, slope, dtype, out1, ld1, out2, ld2, psum, psq,
-                         ntiles_stat, s, nullptr, nullptr, PFA_ACT_NONE);
+                         ntiles_stat, s, nullptr, nullptr, PFA_ACT_NONE, FinishFuse{});
 }
 
 static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels, int n, int n1, const float* bias, int act,
                          float slope, int dtype, void* out1, int ld1, void* out2, int ld2, float* psum, float* psq,
-                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2) {
+                         int* ntiles_stat, pfa_stream s, const float* scale, const float* shift, int act2,
+                         const FinishFuse& fz) {
     PFA_REQUIRE(slab && out1 && splitk >= 1 && pixels > 0 && n > 0 && slab_ld >= n, "pfa_splitk_finish: bad arguments");
     PFA_REQUIRE(n1 >= n || out2 || scale, "pfa_splitk_finish: out2 missing");
     PFA_REQUIRE(dtype == PFA_F32 || dtype == PFA_BF16, "pfa_splitk_finish: bad dtype");
     const bool vec = finish_vec_ok(n, n1, ld1, act) && n1 % 4 == 0 && slab_ld == n;
-    PFA_REQUIRE(!scale || vec, "pfa_gather_gemm: the affine epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 and ld1 == n");
+    PFA_REQUIRE(!(scale || fz.out) || vec,
+                "pfa_gather_gemm: a fused epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 (and ld1 == n for one output)");
     const bool small = !vec && n1 >= n && ld1 <= 16 && !psum;
     const int passes = vec ? finish_passes(n, pixels) : 1;
     const int rpb = vec ? (256 / (n / 4)) * passes : 64;
@@ -1447,10 +1510,10 @@ static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels,
     if (vec) {
         if (dtype == PFA_BF16)
             hipLaunchKernelGGL(k_splitk_finish_vec<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2, fz);
         else
             hipLaunchKernelGGL(k_splitk_finish_vec<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2, fz);
     } else if (small) {
         const int grid = (int)(((size_t)pixels * ld1 + 255) / 256);
         if (dtype == PFA_BF16)
@@ -1508,9 +1571,17 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         int tiles = 0;
         // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n
         const bool aff = a->fuse_out == 3;
+        FinishFuse fz{};
+        if (a->fuse_out == 1 || a->fuse_out == 2) {
+            fz.out = a->fuse_out; fz.act1 = a->fuse_act1; fz.act2 = a->fuse_act2; fz.nreal = k.fuse_nreal;
+            fz.stat_col0 = k.stat_col0; fz.stat_n = k.stat_n;
+            fz.raw = (const char*)a->fuse_raw; fz.g2 = (const char*)a->fuse_g2;
+            fz.scale = a->fuse_scale; fz.shift = a->fuse_shift; fz.mean = a->fuse_mean; fz.invstd = a->fuse_invstd;
+            PFA_REQUIRE(!k.coef_unaligned, "pfa_gather_gemm: fused backward of a K-sliced launch needs 16-byte aligned coefficient arrays");
+        }
         rc = splitk_finish(k.slab, k.slab_ld, k.splitk, k.npix, k.n, k.n1, k.bias, k.act, k.slope, a->dtype, k.out1, k.ld1,
                            k.out2, k.ld2, k.psum, k.psq, &tiles, s, aff ? a->fuse_scale : nullptr,
-                           aff ? a->fuse_shift : nullptr, a->fuse_act2);
+                           aff ? a->fuse_shift : nullptr, a->fuse_act2, fz);
         if (rc) return rc;
         a->ntiles_stat = tiles;
     } else {

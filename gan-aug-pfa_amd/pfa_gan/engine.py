@@ -464,7 +464,8 @@ class GeneratorEngine(_Engine):
                 if L.b is not None:
                     K.colsum(d, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
-            fusable = K.auto_splitk(K.CONV_S2, [d], L.conv.in_channels, (B, h, w)) == 1
+            fusable = K.fuse_ok(K.CONV_S2, [d], L.conv.in_channels, (B, h, w),
+                                single_ld=srcs[0].shape[3] if k == D - 1 else None)
             if k == D - 1:
                 # the only consumer of the innermost conv output is this ReLU: its gradient is final here
                 Ln = self.down[k]
@@ -518,7 +519,7 @@ class GeneratorEngine(_Engine):
             if k > 0:
                 Lp = self.down[k - 1]             # the node this input gradient belongs to
                 hp, wp = H >> k, W >> k
-                if K.auto_splitk(K.TCONV_S2, [dr], src.shape[3], (B, h, w)) == 1:
+                if K.fuse_ok(K.TCONV_S2, [dr], src.shape[3], (B, h, w), single_ld=src.shape[3]):
                     rawp = ctx.buf(f"e{k - 1}.raw", src.shape, dt) if Lp.bn is not None else v["aL"][k - 1]
                     dyp = ctx.buf(f"e{k - 1}.dy", src.shape, dt)
                     st = K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [dyp], (B, h, w), self.ws,
@@ -638,7 +639,7 @@ class DiscriminatorEngine(_Engine):
                 cp = sum(L.in_pad)
                 mode = K.TCONV_S2 if L.stride == 2 else K.CONV_S1_DGRAD
                 grid = (B, ho, wo) if L.stride == 2 else (B, hin, win)
-                if i > 0 and K.auto_splitk(mode, [dr], cp, grid) == 1:
+                if i > 0 and K.fuse_ok(mode, [dr], cp, grid, single_ld=v["a"][i - 1].shape[3]):
                     Lp = self.layers[i - 1]
                     prev = v["a"][i - 1]
                     rawp = ctx.buf(f"c{i - 1}.raw", prev.shape, dt) if Lp.bn is not None else prev

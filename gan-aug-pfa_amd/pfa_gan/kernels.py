@@ -97,6 +97,7 @@ def choose_splitk(mode, M, n, ctot, dtype):
 
 import os as _os
 FUSE_BWD = _os.environ.get("PFA_FUSE_BWD", "1") != "0"     # A/B switch for the fused dgrad epilogue
+FUSE_SPLIT = _os.environ.get("PFA_FUSE_SPLIT", "1") != "0"  # ... and for fusing it into the finish pass of K-sliced launches
 
 
 def auto_splitk(mode, srcs, n, grid):
@@ -107,6 +108,18 @@ def auto_splitk(mode, srcs, n, grid):
         # step, tools/insitu_launches.py) while the separate streaming pass costs ~25 us
         return 0
     return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(s.shape[3] for s in srcs), srcs[0].dtype)
+
+
+def fuse_ok(mode, srcs, n, grid, single_ld=None):
+    """Can the activation / BatchNorm backward ride on this input-gradient launch (gather_gemm(fuse=...))?  Yes for an
+    un-split launch (GEMM epilogue); for a K-sliced one when its finish pass takes the vector path: whole 16-byte column
+    chunks that tile 256 lanes, and unpadded rows if there is a single output (single_ld = its row length)."""
+    sk = auto_splitk(mode, srcs, n, grid)
+    if sk <= 1:
+        return sk == 1
+    if not FUSE_SPLIT:
+        return False
+    return n % 4 == 0 and n // 4 <= 256 and 256 % (n // 4) == 0 and (single_ld is None or single_ld == n)
 
 
 def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None,

@@ -110,7 +110,8 @@ typedef struct pfa_gather_args {
      * apply it in their finish pass, which needs n % 4 == 0, n/4 dividing 256 and ld1 == n; no
      * bias, n1 >= n): y = fuse_scale[n]*acc + fuse_shift[n]; out1 = act(y); out2, if not NULL, = fuse_act2(y) over the
      * same columns (the LeakyReLU and ReLU readers of one encoder activation, models.py:204-208). */
-    /* Fused activation / BatchNorm backward (input-gradient launches, splitk == 1, no bias/act): the chosen output
+    /* Fused activation / BatchNorm backward (input-gradient launches, no bias/act; a K-sliced launch applies it in its
+     * finish pass, which needs n % 4 == 0, n/4 dividing 256 and, with one output, ld1 == n): the chosen output
      * receives dy = act1'(y)*g + act2'(y)*g2 instead of g, with y = scale*raw + shift (scale NULL: y = raw) and raw the
      * conv output that output is the gradient of (same shape).  With mean/invstd, psum/psq receive the per-tile
      * sums of dy and dy*xhat over the fused output's columns (row length = its ld) for pfa_bn_bwd_finalize. */

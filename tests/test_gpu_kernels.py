@@ -322,6 +322,75 @@ def test_affine_epilogue(case, dtype, ws):
             assert float(t[..., co:].float().abs().max()) == 0.0, "pad channels must be written as zeros"
 
 
+FUSED_BWD_CASES = [  # name, N, cin, H, W, Co (columns), K slices, BatchNorm, second gradient, two outputs
+    ("act_only", 2, [64], 16, 16, 64, 1, False, False, False),
+    ("bn", 2, [64], 16, 16, 128, 1, True, False, False),
+    ("bn_g2", 2, [64], 16, 16, 128, 1, True, True, False),
+    ("bn_sliced", 2, [64], 8, 8, 128, 4, True, False, False),            # K-sliced: the finish pass applies it
+    ("bn_g2_sliced", 3, [128], 6, 10, 64, 3, True, True, False),
+    ("act_sliced", 2, [64], 8, 8, 64, 2, False, False, False),
+    ("two_outputs_sliced", 2, [64], 8, 8, 128, 4, True, False, True),    # [plain 64 | fused 64] like the decoder's dgrad
+    ("two_outputs", 2, [64], 16, 16, 128, 1, True, False, True),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", FUSED_BWD_CASES, ids=[c[0] for c in FUSED_BWD_CASES])
+def test_fused_backward_epilogue(case, dtype, ws):
+    """fuse_out = 1|2: the launch computes g = conv(...) and stores dy = LeakyReLU'(y)*g (+ ReLU'(y)*g2) with
+    y = scale*raw + shift, plus the per-column sums of dy and dy*xhat - in the GEMM epilogue, or in the finish pass
+    when the launch is K-sliced."""
+    name, n, cins, h, w, co, slices, bn, with_g2, two = case
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".fx", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".fw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    g = ops.conv2d_fwd(x, wt, None, 2)                                  # [n, co, ho, wo]: the incoming gradient
+    ho, wo = g.shape[2:]
+    wsh, _ = shadows(wt, dtype, cparts=[(c, K.pad_ch(c, dtype)) for c in cins], want=("same",))
+    srcs = [to_nhwc(x, dtype)]
+    c0 = co // 2 if two else 0                                          # first fused column
+    cf = co - c0                                                         # fused columns
+    raw = rnd(fill.uniform(name + ".fraw", (n, cf, ho, wo), -1.0, 1.0), dtype)
+    g2 = rnd(fill.uniform(name + ".fg2", (n, cf, ho, wo), -1.0, 1.0), dtype) if with_g2 else None
+    scale = fill.uniform(name + ".fsc", (cf,), 0.5, 1.5) if bn else np.ones(cf, np.float32)
+    shift = fill.uniform(name + ".fsh", (cf,), -0.3, 0.3) if bn else np.zeros(cf, np.float32)
+    mean = fill.uniform(name + ".fmu", (cf,), -0.2, 0.2)
+    invstd = fill.uniform(name + ".fis", (cf,), 0.5, 2.0)
+    y = raw * scale[None, :, None, None] + shift[None, :, None, None]
+    gf = g[:, c0:]
+    want = np.where(y >= 0, 1.0, 0.2) * gf
+    if with_g2:
+        want = want + (y > 0) * g2
+    outs = [torch.full((n, ho, wo, c0 if two else co), 7.0, dtype=dtype, device="cuda")]
+    if two:
+        outs.append(torch.full((n, ho, wo, cf), 7.0, dtype=dtype, device="cuda"))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    spec = dict(out=2 if two else 1, raw=to_nhwc(raw, dtype), act1=K.ACT_LRELU,
+                g2=to_nhwc(g2, dtype) if with_g2 else None, act2=K.ACT_RELU if with_g2 else K.ACT_NONE)
+    if bn:
+        spec.update(scale=dev(scale), shift=dev(shift), mean=dev(mean), invstd=dev(invstd))
+    before = _lib.launch_count()
+    st = K.gather_gemm(K.CONV_S2, srcs, wsh, co, outs, (n, ho, wo), ws, splitk=slices, fuse=spec)
+    launches = _lib.launch_count() - before
+    assert launches == (2 if slices > 1 else 1)
+    amax = np.abs(g).max()
+    close(from_nhwc(outs[-1], cf), want, dtype, name + ".dy", scale=amax)
+    if two:
+        close(from_nhwc(outs[0], c0), g[:, :c0], dtype, name + ".plain", scale=amax)
+    if bn:
+        part, _, nt = st
+        torch.cuda.synchronize()
+        p = part[: 2 * nt * cf].view(2, nt, cf).double().sum(1).cpu().numpy()
+        got_dy = from_nhwc(outs[-1], cf).astype(np.float64)            # sums of what was stored, before its rounding
+        xhat = (raw - mean[None, :, None, None]) * invstd[None, :, None, None]
+        close(p[0], want.astype(np.float64).sum(axis=(0, 2, 3)), dtype, name + ".sum_dy", scale=np.abs(want).sum(axis=(0, 2, 3)).max())
+        close(p[1], (want.astype(np.float64) * xhat).sum(axis=(0, 2, 3)), dtype, name + ".sum_dy_xhat",
+              scale=np.abs(want * xhat).sum(axis=(0, 2, 3)).max())
+        assert np.isfinite(got_dy).all()
+    else:
+        assert st is None
+
+
 SCATTER_CASES = [  # name, N, cin parts, H, W, Co, bias, act
     ("d1", 2, [64, 64], 8, 8, 3, True, K.ACT_TANH),              # the generator's output layer: two 64-channel sources
     ("d1_ragged", 1, [64, 64], 7, 33, 3, True, K.ACT_TANH),      # H not a multiple of the 6-row tile, W crosses a tile
