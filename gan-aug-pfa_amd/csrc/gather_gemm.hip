@@ -43,7 +43,6 @@ struct GatherK {
     float* psq;
     float* slab;
     int slab_ld;
-    int* tickets;            // in-kernel K-slice reduction: one arrival counter per output tile (nullptr: slab + finish pass)
     int mode, nb, hq, wq, hs, ws;
     int c1, c2, ctot;
     int cpt, cpt_shift, ktot, ksteps;
@@ -705,65 +704,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
         }
     }
 
-    if (p.splitk > 1 && p.tickets) {
-        // In-kernel reduction of the K slices: every slice stores its partial tile (accumulator order: one 16-byte piece
-        // per lane and fragment, whole 128-byte lines per wave instruction) with sc1 stores, drains them, and one lane
-        // takes a ticket on the tile's counter; the workgroup whose ticket is the last one sums ALL slices (its own
-        // included, from memory: a fixed order whatever the arrival order - bitwise reproducible) with sc1 loads and
-        // runs the ordinary epilogue.  No finish pass, no second launch.  Visibility across the per-XCD L2s: sc1 stores,
-        // s_waitcnt vmcnt(0) in every storing wave, workgroup barrier, agent-scope atomic add by one lane; the reader
-        // loads only after its add has returned and uses sc1 loads for every byte (MI355X micro-architecture guide,
-        // "Workgroup dispatch, XCD placement & inter-workgroup visibility", hand-off table row 1).
-        const size_t tile_id = ((size_t)cls * p.mtiles + mt) * p.ntiles + nt;
-        float* part0 = p.slab + tile_id * p.splitk * (size_t)(BM * BN) + (size_t)tid * 4;
-        {
-            float* mine = part0 + (size_t)split * (BM * BN);
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + (a * FM + b) * NT * 4), "v"(acc[a][b]) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* tk = (int*)smem;
-        if (tid == 0) *tk = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*tk != p.splitk - 1) return;
-        if (tid == 0) __hip_atomic_store(p.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < p.splitk; s0 += 2) {
-            // two slices in flight (2 x FN*FM 16-byte loads per lane), added in slice order
-            f32x4 t0[FN][FM], t1[FN][FM];
-            const bool two = s0 + 1 < p.splitk;
-            const float* q0 = part0 + (size_t)s0 * (BM * BN);
-            const float* q1 = part0 + (size_t)(two ? s0 + 1 : s0) * (BM * BN);
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b)
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t0[a][b]) : "v"(q0 + (a * FM + b) * NT * 4) : "memory");
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b)
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t1[a][b]) : "v"(q1 + (a * FM + b) * NT * 4) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b) {
-                    pin(t0[a][b]);
-                    pin(t1[a][b]);
-                    acc[a][b] += t0[a][b];
-                    if (two) acc[a][b] += t1[a][b];
-                }
-        }
-        __syncthreads();        // the ticket word lives in the LDS the statistics reduction below reuses
-    } else if (p.splitk > 1) {
+    if (p.splitk > 1) {
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;
@@ -1216,7 +1157,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     PFA_REQUIRE((a->psum == nullptr) == (a->psq == nullptr), "pfa_gather_gemm: psum/psq must come together");
     k.src1 = (const char*)a->src1; k.src2 = (const char*)a->src2; k.w = (const char*)a->w;
     k.out1 = (char*)a->out1; k.out2 = (char*)a->out2; k.bias = a->bias;
-    k.psum = a->psum; k.psq = a->psq; k.slab = a->slab; k.tickets = a->tickets;
+    k.psum = a->psum; k.psq = a->psq; k.slab = a->slab;
     k.mode = a->mode; k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hs = a->hs; k.ws = a->ws;
     k.c1 = a->c1; k.c2 = a->c2; k.ctot = a->c1 + a->c2;
     k.cpt = k.ctot / ch; k.cpt_shift = ilog2_exact(k.cpt);
@@ -1323,43 +1264,18 @@ inline int fill_params_geometry(const pfa_gather_args* a, GatherK& k, int& class
     return fill_params(&b, k, classes);
 }
 
-// K slices summed inside the launch by the last-arriving workgroup of each tile (k_gather_gemm epilogue) instead of a
-// slab + finish pass: launches on the 256x128 tile - one 8-wave workgroup per CU, the configuration the sc1 hand-off is
-// measured for - when the caller passed a ticket array.  EXPERIMENTAL, off unless pfa_set_knob(3, 1): per kernel it
-// matches the finish pass bit for bit (tests/test_gpu_kernels.py, tools/slice_reduce_stress.py: 0 mismatches in 1800
-// launches), but inside the networks the last workgroup sometimes reads partials that have not landed (the discriminator's
-// c4 forward after the c2 / c3 launches: garbage in ~10 % of the runs, tools/engine_repeat.py) - cause not found - and it
-// buys +0.5 % only - the few reducing workgroups read the partials about as slowly as the finish pass.
-inline bool reduce_in_kernel(const GatherK& k, const TileCfg& cfg) {
-    return g_knob[3] == 1 && k.splitk > 1 && k.tickets != nullptr && cfg.id == 3;
-}
-
 }  // namespace
 
 extern "C" size_t pfa_gather_slab_floats(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (fill_params_geometry(a, k, classes)) return 0;
     if (k.splitk <= 1) return 0;
-    const size_t rows = (size_t)k.splitk * k.npix * k.slab_ld;                       // [splitk][pixels][round4(n)]
-    const TileCfg cfg = choose_cfg(k);
-    // in-kernel reduction: [tile][splitk][bm*bn] in accumulator order
-    const size_t tiles = (size_t)classes * ((k.M + cfg.bm - 1) / cfg.bm) * ((k.n + cfg.bn - 1) / cfg.bn);
-    const size_t frag = tiles * k.splitk * (size_t)cfg.bm * cfg.bn;
-    return rows > frag ? rows : frag;
-}
-
-extern "C" int pfa_gather_ticket_count(const pfa_gather_args* a) {
-    GatherK k; int classes;
-    if (int rc = fill_params_geometry(a, k, classes)) return rc;
-    if (k.splitk <= 1) return 0;
-    const TileCfg cfg = choose_cfg(k);
-    return classes * ((k.M + cfg.bm - 1) / cfg.bm) * ((k.n + cfg.bn - 1) / cfg.bn);
+    return (size_t)k.splitk * k.npix * k.slab_ld;                       // [splitk][pixels][round4(n)]
 }
 
 extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
-    if (reduce_in_kernel(k, choose_cfg(k))) return classes * ((k.M + 255) / 256);
     if (k.splitk > 1) {
         const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act, k.npix);
         return (k.npix + rpb - 1) / rpb;
@@ -1542,9 +1458,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     const TileCfg cfg = choose_cfg(k);
     int rc;
     GatherK kk = k;
-    const bool inred = reduce_in_kernel(k, cfg);
-    if (!inred) kk.tickets = nullptr;
-    if (k.splitk > 1 && !inred) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
+    if (k.splitk > 1) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
     TimedLaunch tl{};
     const bool timing = g_timing;
     if (timing) {
@@ -1567,7 +1481,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         g_timed.push_back(tl);
     }
     if (rc) return rc;
-    if (k.splitk > 1 && !inred) {
+    if (k.splitk > 1) {
         int tiles = 0;
         // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n
         const bool aff = a->fuse_out == 3;

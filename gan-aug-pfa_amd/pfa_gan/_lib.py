@@ -25,7 +25,7 @@ class GatherArgs(Structure):
         ("out1", c_void_p), ("out2", c_void_p), ("psum", c_void_p), ("psq", c_void_p), ("slab", c_void_p),
         ("fuse_out", c_int32), ("fuse_act1", c_int32), ("fuse_act2", c_int32), ("reserved", c_int32),
         ("fuse_raw", c_void_p), ("fuse_g2", c_void_p), ("fuse_scale", c_void_p), ("fuse_shift", c_void_p),
-        ("fuse_mean", c_void_p), ("fuse_invstd", c_void_p), ("tickets", c_void_p),
+        ("fuse_mean", c_void_p), ("fuse_invstd", c_void_p),
     ]
 
 
@@ -69,7 +69,6 @@ PROTOTYPES = {
                                       POINTER(c_int)]),
     "pfa_gather_stat_tiles": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_slab_floats": (c_size_t, [POINTER(GatherArgs)]),
-    "pfa_gather_ticket_count": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_gemm": (c_int, [POINTER(GatherArgs), c_void_p]),
     "pfa_splitk_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p,
                                   c_int, c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), c_void_p]),

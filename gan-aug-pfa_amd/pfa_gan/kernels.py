@@ -64,12 +64,10 @@ class Workspace:
         self.device = device
         self._bufs = {}
 
-    def get(self, name, numel, dtype=torch.float32, zero=False):
-        """zero=True: zero-filled when (re)allocated - for state the kernels themselves keep at zero (ticket counters)."""
+    def get(self, name, numel, dtype=torch.float32):
         buf = self._bufs.get(name)
         if buf is None or buf.numel() < numel or buf.dtype != dtype:
-            make = torch.zeros if zero else torch.empty
-            buf = make(max(int(numel), 1), dtype=dtype, device=self.device)
+            buf = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
             self._bufs[name] = buf
         return buf
 
@@ -154,10 +152,7 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     a.out1, a.out2 = ptr(outs[0]), ptr(outs[1]) if len(outs) > 1 else None
     npix = outs[0].shape[0] * outs[0].shape[1] * outs[0].shape[2]
     if a.splitk > 1:
-        # K slices: partial tiles + one arrival counter per output tile (the last-arriving workgroup of a tile sums the
-        # slices inside the launch where the library supports it, else a finish pass reads the slab)
         a.slab = ptr(ws.get("slab", lib().pfa_gather_slab_floats(ctypes.byref(a))))
-        a.tickets = ptr(ws.get("tickets", lib().pfa_gather_ticket_count(ctypes.byref(a)), torch.int32, zero=True))
     psum = psq = None
     if affine is not None:
         a.fuse_out, a.fuse_act2 = 3, affine[2]

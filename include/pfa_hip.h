@@ -58,7 +58,6 @@ uint64_t pfa_launch_count(void);
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
  * 5 = no K-group pairs, 6 = pairs from four slices on);
- * id 3: 1 = experimental in-kernel reduction of the K slices (pfa_gather_args.tickets); 0 = slab + finish pass;
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
@@ -124,20 +123,12 @@ typedef struct pfa_gather_args {
     const float* fuse_shift;
     const float* fuse_mean;
     const float* fuse_invstd;
-    /* Optional, splitk > 1, EXPERIMENTAL (used only after pfa_set_knob(3, 1)): pfa_gather_ticket_count() int32 arrival
-     * counters, zero before the first call (every launch leaves them zero).  A sliced launch on the 256x128 tile then sums
-     * its K slices itself - the last-arriving workgroup of each output tile adds all slices in slice order and runs the
-     * epilogue - instead of writing [splitk][pixels][n] partials for a second pass (pfa_splitk_finish).  Both sum the
-     * slices in ascending order (equal bits without a bias; the finish pass starts from the bias, the in-kernel sum adds it
-     * last).  Tickets and slab must not be shared by launches that may run concurrently. */
-    int32_t* tickets;
 } pfa_gather_args;
 
 /* Tiles of partial statistics a call will write (rows of psum/psq) for this geometry. */
 int pfa_gather_stat_tiles(const pfa_gather_args* a);
-/* Floats the slab of this call must hold (0 when splitk <= 1), and the length of its ticket array. */
+/* Floats the slab of this call must hold (0 when splitk <= 1). */
 size_t pfa_gather_slab_floats(const pfa_gather_args* a);
-int pfa_gather_ticket_count(const pfa_gather_args* a);
 int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s);
 
 /* Sum split-K slabs [splitk][pixels][slab_ld], add bias, emit statistics partials, activate, store. */

@@ -37,6 +37,6 @@ def test_argument_validation_needs_no_gpu():
 def test_struct_layout_matches_the_header():
     import ctypes
     # 18 int32/float fields then 9 pointers; 16 x 4 + 2 x 4 = 72 bytes of scalars, 8-byte aligned pointers after
-    assert ctypes.sizeof(_lib.GatherArgs) == 72 + 9 * 8 + 16 + 7 * 8
+    assert ctypes.sizeof(_lib.GatherArgs) == 72 + 9 * 8 + 16 + 6 * 8
     assert ctypes.sizeof(_lib.WgradArgs) == 18 * 4 + 6 * 8
     assert ctypes.sizeof(_lib.ScatterArgs) == 12 * 4 + 5 * 8          # pfa_scatter_args

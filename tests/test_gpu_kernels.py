@@ -197,81 +197,6 @@ def test_ring_loops_of_the_256x128_tile(case, loop, ws):
           scale=np.abs(want).sum(axis=(0, 2, 3)).max())
 
 
-SLICE_CASES = [  # name, kind, N, cin parts, H, W, Co, stride, splitk, bias, act
-    ("conv_s2_x2", "conv", 2, [64], 32, 32, 128, 2, 2, False, K.ACT_NONE),
-    ("conv_s2_x5_bias_lrelu", "conv", 3, [128], 18, 22, 200, 2, 5, True, K.ACT_LRELU),     # odd slice count, ragged tile
-    ("conv_s1_x8", "conv", 1, [128], 9, 11, 256, 1, 8, False, K.ACT_RELU),
-    ("tconv_cat_x4", "tconv", 2, [128, 128], 5, 8, 136, 2, 4, False, K.ACT_NONE),
-]
-
-
-@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
-@pytest.mark.parametrize("case", SLICE_CASES, ids=[c[0] for c in SLICE_CASES])
-def test_in_kernel_slice_reduction(case, dtype, ws):
-    """Experimental pfa_set_knob(3, 1): K-sliced launches on the 256x128 tile sum their slices inside the launch
-    (last-arriving workgroup per tile, sc1 hand-off): same bits as the default slab + finish pass, oracle-close, tickets
-    left at zero, repeatable launch after launch."""
-    name, kind, n, cins, h, w, co, stride, splitk, bias, act = case
-    ci = sum(cins)
-    x = rnd(fill.uniform(name + ".x", (n, ci, h, w)), dtype)
-    srcs, o = [], 0
-    for c in cins:
-        srcs.append(to_nhwc(x[:, o:o + c], dtype))
-        o += c
-    b = fill.uniform(name + ".b", (co,), -0.5, 0.5) if bias else None
-    if kind == "conv":
-        wt = rnd(fill.uniform(name + ".w", (co, ci, 4, 4), -0.25, 0.25), dtype)
-        raw = ops.conv2d_fwd(x, wt, b, stride)
-        wsh, _ = shadows(wt, dtype, cparts=[(c, K.pad_ch(c, dtype)) for c in cins], want=("same",))
-        mode, grid = (K.CONV_S2 if stride == 2 else K.CONV_S1), (n,) + raw.shape[2:]
-    else:
-        wt = rnd(fill.uniform(name + ".w", (ci, co, 4, 4), -0.25, 0.25), dtype)
-        raw = ops.convT2d_fwd(x, wt, b)
-        _, wsh = shadows(wt, dtype, want=("tr",))
-        mode, grid = K.TCONV_S2, (n, h, w)
-    want = ops.leaky_relu(raw) if act == K.ACT_LRELU else ops.relu(raw) if act == K.ACT_RELU else raw
-    bt = torch.from_numpy(b).cuda() if bias else None
-    lib = _lib.lib()
-    shape = (n,) + raw.shape[2:] + (K.pad_ch(co, dtype),)
-
-    def run(finish_pass):
-        out = torch.full(shape, 7.0, dtype=dtype, device="cuda")
-        lib.pfa_set_knob(6, 1)
-        lib.pfa_set_knob(3, 0 if finish_pass else 1)
-        try:
-            before = _lib.launch_count()
-            st = K.gather_gemm(mode, srcs, wsh, co, [out], grid, ws, bias=bt, act=act, stats=True, splitk=splitk)
-            launches = _lib.launch_count() - before
-        finally:
-            lib.pfa_set_knob(6, 0)
-            lib.pfa_set_knob(3, 0)
-        psum, psq, nt = st
-        torch.cuda.synchronize()
-        s = psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
-        q = psq[: nt * co].view(nt, co).double().sum(0).cpu().numpy()
-        return out, s, q, launches
-
-    out_a, s_a, q_a, l_a = run(False)
-    out_b, s_b, q_b, l_b = run(True)
-    out_c, _, _, _ = run(False)
-    assert (l_a, l_b) == (1, 2), "one launch with the in-kernel reduction, kernel + finish pass without"
-    if bias:        # the finish pass starts its sum from the bias, the in-kernel one adds it last
-        close(out_a.float().cpu().numpy(), out_b.float().cpu().numpy(), dtype, name + ".paths")
-    else:
-        assert torch.equal(out_a, out_b), "in-kernel reduction and finish pass must agree bit for bit"
-    assert torch.equal(out_a, out_c), "repeatable"
-    assert int(ws.get("tickets", 1, torch.int32, zero=True).abs().max()) == 0, "tickets must be left at zero"
-    close(from_nhwc(out_a, co), want, dtype, name)
-    if K.pad_ch(co, dtype) > co:
-        assert float(out_a[..., co:].float().abs().max()) == 0.0
-    if not bias:
-        close(s_a, raw.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
-              scale=np.abs(raw).sum(axis=(0, 2, 3)).max())
-        close(q_a, (raw.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
-        np.testing.assert_allclose(s_a, s_b, rtol=1e-5, atol=1e-4)
-        np.testing.assert_allclose(q_a, q_b, rtol=1e-5, atol=1e-4)
-
-
 AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs, K slices
     ("enc_small", "conv", 2, [8], 16, 16, 8, True, 1),             # narrow staging, 256x16 tile
     ("enc_mid", "conv", 2, [64], 32, 32, 96, True, 1),             # 128x128 tile, ragged columns

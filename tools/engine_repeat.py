@@ -1,5 +1,5 @@
 """Run the discriminator engine's train-mode forward repeatedly on one input and report which named buffers differ from the
-first run (developer tool; PFA_KNOBS=3=1 selects the experimental in-kernel K-slice reduction)."""
+first run (developer tool)."""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import torch
@@ -16,9 +16,6 @@ first, diff = None, {}
 for it in range(reps):
     eng.forward(x, ctx, train=True)
     torch.cuda.synchronize()
-    tk = eng.ws._bufs.get('tickets')
-    if tk is not None and int(tk.abs().max()) != 0:
-        print('iteration', it, 'tickets left nonzero:', tk[:16].tolist())
     snap = {k: v.detach().float().clone() for k, v in ctx._t.items()}
     if first is None:
         first = snap

@@ -1,5 +1,5 @@
 """Repeat one fused step from the same state many times and report run-to-run deviations (developer tool): a stale or
-racy hand-off shows as an outlier.  PFA_KNOBS selects the code path (3=1: experimental in-kernel reduction of the K slices)."""
+racy hand-off shows as an outlier.  PFA_KNOBS selects the code path."""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np, torch
