@@ -206,14 +206,15 @@ class _Engine:
             self._scratch = self.new_ctx()
         return self._scratch
 
-    def _shadow_table(self):
-        """Device-resident descriptor table so that ALL layers re-emit their shadows in two launches."""
+    def _shadow_table(self, layers=None):
+        """Device-resident descriptor table so that ALL layers (or the given ones) re-emit their shadows in one launch."""
         import ctypes
         from ._lib import ShadowDesc, lib
-        n = len(self.layers)
+        layers = self.layers if layers is None else layers
+        n = len(layers)
         arr = (ShadowDesc * n)()
         sb = tb = 0
-        for i, L in enumerate(self.layers):
+        for i, L in enumerate(layers):
             (c1r, c1p), (c2r, c2p) = L.cparts[0], (L.cparts[1] if len(L.cparts) > 1 else (0, 0))
             a, b = ctypes.c_int(0), ctypes.c_int(0)
             K.check(lib().pfa_shadow_blocks(L.rows, c1p, c2p, L.rows_p, ctypes.byref(a), ctypes.byref(b)), "pfa_shadow_blocks")
@@ -238,6 +239,23 @@ class _Engine:
             K.check(K.lib().pfa_weight_shadow_batch(tab.data_ptr(), n, sb, tb, K.dt_code(self.dtype), K.stream()),
                     "pfa_weight_shadow_batch")
             self._versions = versions
+
+    def refresh_shadows_range(self, lo, hi):
+        """Re-emit the kernel-side copies of the layers whose weights lie in [lo, hi) of the parameter arena (one bucket of
+        grad_buckets(): the fused trainer updates and refreshes bucket by bucket while the backward is still running)."""
+        tabs = self.__dict__.setdefault("_range_tables", {})
+        if (lo, hi) not in tabs:
+            sub = [L for L in self.layers if lo <= self.flat.slots[id(L.w)][0] < hi]
+            tabs[(lo, hi)] = self._shadow_table(sub) if sub else None
+        if tabs[(lo, hi)] is not None:
+            tab, n, sb, tb = tabs[(lo, hi)]
+            K.check(K.lib().pfa_weight_shadow_batch(tab.data_ptr(), n, sb, tb, K.dt_code(self.dtype), K.stream()),
+                    "pfa_weight_shadow_batch")
+
+    def shadows_refreshed(self):
+        """All ranges have been re-emitted for the current parameters (bookkeeping of refresh_shadows)."""
+        self.bn_epoch += 1
+        self._versions = (self.flat.epoch,) + tuple(L.w._version for L in self.layers)
 
     # BatchNorm plumbing ------------------------------------------------------------
     @staticmethod
@@ -438,7 +456,8 @@ class GeneratorEngine(_Engine):
     def backward(self, ctx, dpre, garena, side=None, bucket_ready=None):
         """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena.
         side: optional second stream for the parameter-gradient kernels (join it before using garena).
-        bucket_ready(i): called when grad_buckets()[0][i] has had all its kernels issued (data parallel overlap)."""
+        bucket_ready(i): called when every kernel that writes grad_buckets()[0][i] or reads its parameters has been issued
+        (the caller may all-reduce that range and update its parameters under the rest of the backward)."""
         if not ctx.v.get("train", False):
             raise PfaError("generator backward needs a training-mode forward")
         D, dt = self.D, self.dtype
@@ -514,8 +533,6 @@ class GeneratorEngine(_Engine):
                 if L.b is not None:
                     K.colsum(dr, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
-            if bucket_ready is not None and k == mid_level and k > 0:
-                bucket_ready(1)
             if k > 0:
                 Lp = self.down[k - 1]             # the node this input gradient belongs to
                 hp, wp = H >> k, W >> k
@@ -529,6 +546,9 @@ class GeneratorEngine(_Engine):
                 else:
                     g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                     K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
+            # (after this level's input gradient, the last reader of its weights: the caller may update the bucket now)
+            if bucket_ready is not None and k == mid_level and k > 0:
+                bucket_ready(1)
         if bucket_ready is not None:
             bucket_ready(2 if mid_level > 0 else 1)
 

@@ -21,6 +21,10 @@ BETAS = (0.5, 0.999)   # train_gan.py:30,140-141
 AUTO_GRAPH_PIXELS = 2 * 256 * 256      # use_graph="auto": hipGraph replay at or below this many pixels per batch
 
 
+import os as _os
+BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
+
+
 class FusedAdam(torch.optim.Optimizer):
     """optim.Adam(lr, betas) semantics (weight_decay 0, amsgrad off) as one pfa_adam launch per network.
 
@@ -80,6 +84,22 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.steps,
                    grad_scale=grad_scale, g2=g2)
+
+    @torch.no_grad()
+    def step_begin(self):
+        """First half of a step taken range by range (step_range): one step count for all ranges."""
+        self.flat()
+        self.steps += 1
+        self._flat.epoch += 1
+
+    @torch.no_grad()
+    def step_range(self, lo, hi, grad_scale=1.0):
+        """Adam on elements [lo, hi) of the arena (16-byte aligned bounds: parameter starts) with the step count of the
+        last step_begin().  The fused trainer updates a bucket as soon as its gradients are final."""
+        flat = self.flat()
+        g = self.param_groups[0]
+        K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
+               g["eps"], self.steps, grad_scale=grad_scale)
 
     def state_dict(self):
         self.flat()
@@ -219,10 +239,32 @@ class GanTrainer:
         garena = self.opt_g.flat().grad
         self._works = []
         hook = None
-        if self.pg is not None and self.side is not None and not graph_safe:
-            buckets = G.grad_buckets()[0]
-            main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream()
+        buckets = G.grad_buckets()[0]
+        bucketed = BUCKET_UPDATE and self.side is not None and self.side2 is not None and not graph_safe
+        if bucketed:
+            # Update bucket by bucket while the backward is still running: a bucket of the gradient arena is final once
+            # the side stream (weight gradients) and the main stream (BatchNorm gamma/beta gradients) reach the hook.
+            # The second side stream - idle during the generator backward - then takes the bucket: [all-reduce over the
+            # ranks ->] Adam on that range -> re-emit the kernel-side copies of its layers.  The decoder's bucket (63 % of
+            # the parameters) is updated under the encoder backward; only the last, small bucket is left for the tail.
+            self.opt_g.step_begin()
+            scale = 1.0 / self.world
 
+            def hook(i):
+                lo, hi = buckets[i]
+                if hi <= lo:
+                    return
+                self.side2.wait_stream(main)
+                self.side2.wait_stream(self.side)
+                with torch.cuda.stream(self.side2):
+                    if self.pg is not None:
+                        # enqueued behind side2, runs on the communicator's stream; side2 (not the weight-gradient
+                        # stream) waits for it
+                        torch.distributed.all_reduce(garena[lo:hi], group=self.pg, async_op=True).wait()
+                    self.opt_g.step_range(lo, hi, grad_scale=scale)
+                    G.refresh_shadows_range(lo, hi)
+        elif self.pg is not None and self.side is not None and not graph_safe:
             def hook(i):
                 # bucket i is complete once the side stream (weight gradients) and the main stream (BatchNorm
                 # gamma/beta gradients) reach this point; the RCCL collective is enqueued behind the side stream
@@ -236,13 +278,20 @@ class GanTrainer:
         G.backward(self.gctx, dpre, garena, side=self.side, bucket_ready=hook)
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        if bucketed:
+            torch.cuda.current_stream().wait_stream(self.side2)
+            G.shadows_refreshed()
         for w in self._works:
             w.wait()                 # the current stream waits for the collective; no host sync
         self._g_reduced = hook is not None
+        self._g_updated = bucketed
 
     def _g_update(self, graph_safe):
-        self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
-        self.G.refresh_shadows(force=True)
+        if getattr(self, "_g_updated", False):       # already updated bucket by bucket during the backward
+            self._g_updated = False
+        else:
+            self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
+            self.G.refresh_shadows(force=True)
         self.loss_sums += self.losses
 
     def _allreduce(self, opt):
