@@ -6,7 +6,7 @@ import torch
 from pfa_gan import kernels as K
 here = os.path.dirname(os.path.abspath(__file__))
 proto = ctypes.CDLL(os.path.join(here, "libpfa_proto.so"))
-proto.pfa_proto_conv_s1_patch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6 + [ctypes.c_void_p]
+proto.pfa_proto_conv_s1_patch.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_void_p]
 proto.pfa_proto_conv_s1_patch.restype = ctypes.c_int
 dt = torch.bfloat16
 ws = K.Workspace(torch.device('cuda'))
@@ -19,7 +19,7 @@ for nb, hin, cin, n in ((2, 9, 64, 128), (3, 20, 128, 256), (16, 32, 256, 512)):
     K.gather_gemm(K.CONV_S1, [x], w, n, [ref], (nb, hin - 1, hin - 1), ws, splitk=1)
     for stag in (0, 1):
         out.fill_(7.0)
-        rc = proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, stag,
+        rc = proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, stag, 0,
                                            torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert rc == 0, rc
@@ -37,7 +37,11 @@ for nb, hin, cin, n in ((2, 9, 64, 128), (3, 20, 128, 256), (16, 32, 256, 512)):
         return e0.elapsed_time(e1) * 1e3 / reps
     flop = 2.0 * nb * (hin - 1) ** 2 * n * 16 * cin
     t_ref = timeit(lambda: K.gather_gemm(K.CONV_S1, [x], w, n, [ref], (nb, hin - 1, hin - 1), ws, splitk=1))
-    ts = [timeit(lambda st=st: proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, st,
+    ts = [timeit(lambda st=st: proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, st, 0,
                                                              torch.cuda.current_stream().cuda_stream)) for st in (0, 1)]
     print(f"   product {t_ref:7.1f} us ({flop / t_ref / 1e6:5.0f} TF/s)   patch {ts[0]:7.1f} us ({flop / ts[0] / 1e6:5.0f} TF/s)"
           f"   patch + staggered phases {ts[1]:7.1f} us ({flop / ts[1] / 1e6:5.0f} TF/s)")
+    if nb == 16:      # ablations of the plain loop on the c4 shape (results are wrong when a bit is set)
+        lab = {0: "full", 4: "-dma", 1: "-mfma", 2: "-ldsreads", 5: "-mfma,dma (reads only)", 6: "-reads,dma (mfma only)", 3: "-mfma,reads (dma only)", 7: "empty loop"}
+        print("   ablations:", "  ".join(f"[{lab[d]}: " + "%.1f" % timeit(lambda d=d: proto.pfa_proto_conv_s1_patch(
+            x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, 0, d, torch.cuda.current_stream().cuda_stream)) + "]" for d in lab))

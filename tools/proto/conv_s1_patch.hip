@@ -34,6 +34,7 @@ struct ProtoK {
     const char* w;       // [n][16][cin] bf16 (the product's "same" weight layout)
     char* out;           // [nb][hout][wout][n] bf16
     int nb, hin, win, cin, n, hout, wout, tiles_y, ntiles;
+    int dbg;             // ablation bits (results are wrong when set): 1 no MFMA, 2 no LDS fragment reads after step 0, 4 no DMA after the prologue
 };
 
 constexpr int TY = 8, TX = 32;                    // output patch of a workgroup: 256 pixels
@@ -183,16 +184,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         else if (prev_patch_piece) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        prev_patch_piece = tap < PPASS && chunk + 1 < nchunks;
+        prev_patch_piece = tap < PPASS && chunk + 1 < nchunks && !(p.dbg & 4);
         if (prev_patch_piece) stage_patch_piece(chunk + 1, tap);
-        if (i + 2 < nsteps) stage_w(i + 2, (i + 2) % 3);
+        if (i + 2 < nsteps && !(p.dbg & 4)) stage_w(i + 2, (i + 2) % 3);
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(i, wf, af);
+        if (!(p.dbg & 2) || i == 0) read_frags(i, wf, af);
         WAIT_LGKM(8);
-        mfma_half(wf, af, 0);
+        if (!(p.dbg & 1)) mfma_half(wf, af, 0);
         __builtin_amdgcn_sched_barrier(0);
         WAIT_LGKM(0);
-        mfma_half(wf, af, 1);
+        if (!(p.dbg & 1)) mfma_half(wf, af, 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     }
@@ -216,12 +217,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 
 // src [nb][hin][win][cin] bf16, w [n][16][cin] bf16, out [nb][hin-1][win-1][n] bf16; cin % 64 == 0, n % 128 == 0, win - 1 <= 32
 extern "C" int pfa_proto_conv_s1_patch(const void* src, const void* w, void* out, int nb, int hin, int win, int cin, int n,
-                                       int staggered, void* stream) {
+                                       int staggered, int dbg, void* stream) {
     if (!src || !w || !out || cin % 64 || n % 128 || win - 1 > TX || hin < 2 || win < 2) return -1;
     ProtoK k;
     k.src = (const char*)src; k.w = (const char*)w; k.out = (char*)out;
     k.nb = nb; k.hin = hin; k.win = win; k.cin = cin; k.n = n; k.hout = hin - 1; k.wout = win - 1;
-    k.tiles_y = (k.hout + TY - 1) / TY; k.ntiles = n / 128;
+    k.tiles_y = (k.hout + TY - 1) / TY; k.ntiles = n / 128; k.dbg = dbg;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_s1_patch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
