@@ -1,0 +1,260 @@
+// Stride-1 4x4 convolution forward (PFA_CONV_S1: the discriminator's c4, models.py:237-241) with the input PATCH kept in LDS.
+//
+// pfa_gather_gemm stages, for every (tap, channel chunk) K-step, one 128-byte piece per output pixel: with stride 1 the 16
+// taps re-fetch the same input pixels 16 times and the K-loop is bound by the L2->LDS instruction rate.
+// Here a workgroup owns an 8 x 32 patch of output pixels of one image and 128 output channels.  It stages the
+// (8+3) x (32+3) input pixels of a 64-channel chunk ONCE - double-buffered, 7 DMA pieces per wave and chunk, one per tap
+// step of the previous chunk - and walks the 16 taps inside LDS; only the weight tile (128 rows x 128 B per step, 2 pieces)
+// streams through a 3-stage ring with a counted vmcnt.  DMA instructions per K-step and wave: 2.4 instead of 6.
+// A patch pixel occupies 144 B (128 + one unused piece): 16 consecutive pixels then fall on 16 distinct bank groups for
+// every channel chunk without an XOR swizzle, so the tap shift is a wave-uniform address offset (one VALU add per read).
+// The two waves of every SIMD (w and w + 4) run in opposite phases - fragment reads + DMA issue + counted wait | 32 MFMAs -
+// swapping at every barrier, the late group one barrier behind (the staggered ring of gather_gemm.hip, which pays off
+// once the read phase is this light).  c4 forward, 16 x 32x32x256 -> 31x31x512: 64 us against 89 us (1.0 PF/s).
+//
+// Called by pfa_gather_gemm for the launches it fits (conv_s1_patch_ok); results equal the implicit GEMM's up to the order
+// of the float32 sums (channel chunk outer, tap inner instead of tap outer).
+#include "pfa_common.h"
+
+namespace {
+
+#define PATCH_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
+template <int OFF> __device__ __forceinline__ bf16x8 lds_read16o(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(sh);
+}
+__device__ __forceinline__ float row_sum16(float v) {      // sum over a DPP row, valid in its last lane
+    v = dpp_add<0x111>(v);
+    v = dpp_add<0x112>(v);
+    v = dpp_add<0x114>(v);
+    v = dpp_add<0x118>(v);
+    return v;
+}
+
+struct PatchK {
+    const char* src;     // [nb][hin][win][cin] bf16
+    const char* w;       // [n][16][cin] bf16
+    char* out;           // [nb][hout][wout][n] bf16
+    float* psum;         // optional [nb * tiles_y][n] partial sums / sums of squares
+    float* psq;
+    int nb, hin, win, cin, n, hout, wout, tiles_y, ntiles, nwg;
+};
+
+constexpr int TY = 8, TX = 32;                    // output patch of a workgroup: 256 pixels
+constexpr int PH = TY + 3, PW = TX + 3;           // input patch with halo
+constexpr int PSLOTS = PH * PW;                   // 385 pixels
+constexpr int PSTRIDE = 144;                      // bytes per patch pixel (see the header)
+constexpr int PPASS = 7;                          // 7 x 512 lanes x 16 B >= 385 x 144 B
+constexpr int PATCH_BYTES = PPASS * 512 * 16;     // 57,344 (padded: every lane of every pass writes)
+constexpr int W_BYTES = 128 * 128;
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + 3 * W_BYTES;      // 163,840: the whole LDS of a CU
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_s1_patch(const PatchK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;                 // 4 x 2 waves, 64 pixels x 64 channels per wave
+    const int lrow = lane & 15, kk = lane >> 4;
+    unsigned wid = xcd_remap(blockIdx.x, p.nwg);             // an XCD takes a contiguous run: the n-tiles of a patch together
+    const int nt = wid % p.ntiles; wid /= p.ntiles;
+    const int ty = wid % p.tiles_y, img = wid / p.tiles_y;
+    const int oy0 = ty * TY, n0 = nt * 128;
+    const char* zero = (const char*)g_pfa_zero_page;
+
+    // ---- patch staging: this lane's 7 pieces (9 pieces per pixel, the ninth unused)
+    unsigned poff[PPASS];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) {
+        const int q = j * 512 + tid, slot = q / 9, g = q - slot * 9;
+        const int py = slot / PW, px = slot - py * PW;
+        const int iy = oy0 - 1 + py, ix = px - 1;
+        const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+        poff[j] = ok ? (unsigned)((((img * p.hin + iy) * p.win + ix) * p.cin + g * 8) * 2) : 0u;
+        pok |= ok ? (1u << j) : 0u;
+    }
+    auto stage_patch_piece = [&](int chunk, int j) {
+        const char* gp = ((pok >> j) & 1u) ? p.src + poff[j] + chunk * 128 : zero;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    // ---- weight staging: 2 pieces per step (rows r0 + 64 i), chunk slot cs holds source chunk cs ^ swz(row)
+    const int cs = tid & 7, r0 = tid >> 3;
+    const int wg = cs ^ ((r0 >> 1) & 7);
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * p.cin + wg * 8) * 2);
+    auto stage_w = [&](int step, int buf) {                 // step = chunk * 16 + tap
+        const int chunk = step >> 4, tap = step & 15;
+        char* wb = smem + 2 * PATCH_BYTES + buf * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* gp = p.w + woff[i] + (tap * p.cin + chunk * 64) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // activation fragment b of this wave = 16 consecutive output pixels of patch row wm*2 + b/2
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    unsigned abyte[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) abyte[b] = ((wm * 2 + (b >> 1)) * PW + (b & 1) * 16 + lrow) * PSTRIDE + kk * 16;
+    unsigned wfb[2];
+    {
+        const unsigned sw = (lrow >> 1) & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wfb[h] = lds0 + 2 * PATCH_BYTES + (wn * 64 + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
+    }
+
+    const int nchunks = p.cin / 64, nsteps = nchunks * 16;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) stage_patch_piece(0, j);
+    stage_w(0, 0);
+    stage_w(1, 1);                                           // nsteps >= 16
+
+    // Step i, read phase: fragments of stage i; DMA of [one patch piece of the next chunk] + weight stage i+2; counted
+    // wait for weight stage i+1 (everything older - the patch pieces too - has then landed); every read retired ->
+    // barrier -> MFMA phase -> barrier.  Barrier numbering as in gather_gemm.hip's staggered ring: a stage is waited
+    // for before the first barrier of the step before its use, a buffer is re-filled after the second barrier of the
+    // step of its last use, which the other group reaches only after retiring its reads.
+    bf16x8 wf[2][4], af[2][4];
+    const bool late = wave >= 4;
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // patch 0 and weight stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nsteps; ++i) {
+        const int chunk = i >> 4, tap = i & 15;
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned tb = lds0 + (chunk & 1) * PATCH_BYTES + ((tap >> 2) * PW + (tap & 3)) * PSTRIDE;
+            const unsigned rb = (i % 3) * W_BYTES;
+            const unsigned w0 = wfb[0] + rb, w1 = wfb[1] + rb;
+            wf[0][0] = lds_read16o<0>(w0); wf[0][1] = lds_read16o<2048>(w0); wf[0][2] = lds_read16o<4096>(w0); wf[0][3] = lds_read16o<6144>(w0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) af[0][b] = lds_read16o<0>(abyte[b] + tb);
+            wf[1][0] = lds_read16o<0>(w1); wf[1][1] = lds_read16o<2048>(w1); wf[1][2] = lds_read16o<4096>(w1); wf[1][3] = lds_read16o<6144>(w1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) af[1][b] = lds_read16o<64>(abyte[b] + tb);
+        }
+        const bool pp = tap < PPASS && chunk + 1 < nchunks;
+        if (pp) stage_patch_piece(chunk + 1, tap);
+        if (i + 2 < nsteps) {
+            stage_w(i + 2, (i + 2) % 3);
+            if (pp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PATCH_WAIT_LGKM(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pin(wf[h][a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pin(af[h][b]);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][a], af[h][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: lane holds D[channel = .. + 4 kk + r][pixel = .. + lrow]; pixels outside the image (the 32nd column of
+    //      a 31-wide map, rows past the last one) hold sums over real data and are masked here
+    bool valid[4];
+    size_t opix[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int oy = oy0 + wm * 2 + (b >> 1), ox = (b & 1) * 16 + lrow;
+        valid[b] = oy < p.hout && ox < p.wout;
+        opix[b] = valid[b] ? (size_t)(img * p.hout + oy) * p.wout + ox : 0;
+    }
+    if (p.psum) {
+        __syncthreads();                                   // every wave is done with the staging buffers
+        float* red = (float*)smem;                         // [2][4 wm][128]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { const float v = valid[b] ? acc[a][b][r] : 0.f; s += v; q += v * v; }
+                s = row_sum16(s);
+                q = row_sum16(q);
+                if (lrow == 15) {
+                    const int nl = wn * 64 + a * 16 + 4 * kk + r;
+                    red[wm * 128 + nl] = s;
+                    red[(4 + wm) * 128 + nl] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s += red[i * 128 + tid]; q += red[(4 + i) * 128 + tid]; }
+            const size_t trow = (size_t)img * p.tiles_y + ty;
+            p.psum[trow * p.n + n0 + tid] = s;
+            p.psq[trow * p.n + n0 + tid] = q;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (!valid[b]) continue;
+        char* orow = p.out + opix[b] * p.n * 2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int col = n0 + wn * 64 + a * 16 + 4 * kk;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[a][b][r];
+            *(bf16x4*)(orow + col * 2) = o;
+        }
+    }
+}
+
+}  // namespace
+
+// Geometry the patch kernel is built for (the caller has already checked: PFA_CONV_S1, bf16, one source, one unpadded
+// output, no bias / activation / fused epilogue, no K slices).
+bool pfa_conv_s1_patch_ok(int nb, int hin, int win, int cin, int n, int* stat_tiles) {
+    if (cin % 64 || n % 128 || win - 1 > TX || hin < 2 || win < 2) return false;
+    if (stat_tiles) *stat_tiles = nb * ((hin - 1 + TY - 1) / TY);
+    return true;
+}
+
+int pfa_conv_s1_patch(const void* src, const void* w, void* out, float* psum, float* psq, int nb, int hin, int win,
+                      int cin, int n, hipStream_t st) {
+    PatchK k;
+    k.src = (const char*)src; k.w = (const char*)w; k.out = (char*)out; k.psum = psum; k.psq = psq;
+    k.nb = nb; k.hin = hin; k.win = win; k.cin = cin; k.n = n; k.hout = hin - 1; k.wout = win - 1;
+    k.tiles_y = (k.hout + TY - 1) / TY; k.ntiles = n / 128;
+    k.nwg = nb * k.tiles_y * k.ntiles;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_conv_s1_patch, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_conv_s1_patch, dim3(k.nwg), dim3(512), LDS_BYTES, st, k);
+    PFA_LAUNCHED("k_conv_s1_patch");
+    return 0;
+}

@@ -41,6 +41,11 @@ extern std::atomic<uint64_t> g_pfa_launches;
         if (e__ != hipSuccess) PFA_FAIL((int)e__, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// csrc/conv_patch.hip: stride-1 convolution forward with the input patch kept in LDS (dispatched by pfa_gather_gemm)
+bool pfa_conv_s1_patch_ok(int nb, int hin, int win, int cin, int n, int* stat_tiles);
+int pfa_conv_s1_patch(const void* src, const void* w, void* out, float* psum, float* psq, int nb, int hin, int win, int cin,
+                      int n, hipStream_t st);
+
 static inline int pfa_ch(int dtype) { return dtype == PFA_BF16 ? 8 : 4; }
 static inline int pfa_esize(int dtype) { return dtype == PFA_BF16 ? 2 : 4; }
 static inline int ilog2_exact(int v) {  // log2 if power of two else -1

@@ -104,6 +104,46 @@ def test_conv_forward(case, dtype, ws):
     close(q, (raw.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
 
 
+PATCH_CASES = [  # name, N, Ci, H, W, Co
+    ("c4_like", 2, 64, 17, 19, 128),          # ragged patch rows (16 -> two 8-row tiles) and columns (18 of 32)
+    ("full_width", 3, 128, 12, 33, 256),      # 32 output columns: the whole patch width; two channel chunks, two n-tiles
+    ("one_row", 1, 256, 2, 5, 128),           # a single output row
+    ("tall", 1, 64, 40, 9, 128),              # five row tiles, the last one ragged
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
+def test_conv_s1_patch_kernel(case, ws):
+    """Stride-1 forward convolutions (the discriminator's c4) take the patch kernel of conv_patch.hip when they are large
+    enough; pfa_set_knob(3, 2) routes these small ones there too.  Same oracle, same statistics contract as the
+    implicit GEMM, and the implicit GEMM's result up to the order of the float32 sums."""
+    name, n, ci, h, w, co = case
+    dtype = torch.bfloat16
+    x = rnd(fill.uniform(name + ".px", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".pw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    want = ops.conv2d_fwd(x, wt, None, 1)
+    same, _ = shadows(wt, dtype, cparts=[(ci, ci)], want=("same",))
+    ho, wo = want.shape[2:]
+    lib = _lib.lib()
+    outs, stats = [], []
+    for knob in (2, 1):                      # patch kernel, then the implicit GEMM
+        out = torch.full((n, ho, wo, co), 7.0, dtype=dtype, device="cuda")
+        lib.pfa_set_knob(3, knob)
+        try:
+            psum, psq, nt = K.gather_gemm(K.CONV_S1, [to_nhwc(x, dtype)], same, co, [out], (n, ho, wo), ws, stats=True, splitk=1)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(3, 0)
+        assert kernel.startswith("k_conv_s1_patch") == (knob == 2), kernel
+        torch.cuda.synchronize()
+        outs.append(out)
+        stats.append((psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy(), psq[: nt * co].view(nt, co).double().sum(0).cpu().numpy()))
+    close(from_nhwc(outs[0], co), want, dtype, name)
+    close(from_nhwc(outs[0], co), from_nhwc(outs[1], co), dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
+    close(stats[0][0], want.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum", scale=np.abs(want).sum(axis=(0, 2, 3)).max())
+    close(stats[0][1], (want.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
+
+
 CONVT_FWD = [  # name, N, cin parts, H, W, Co, bias, act, splitk
     ("d7_like", 2, [16], 1, 1, 16, False, K.ACT_NONE, None),
     ("mid_cat", 2, [16, 16], 4, 4, 8, False, K.ACT_NONE, None),

@@ -17,7 +17,7 @@ for nb, hin, cin, n in ((2, 9, 64, 128), (3, 20, 128, 256), (16, 32, 256, 512)):
     ref = torch.empty(nb, hin - 1, hin - 1, n, device='cuda', dtype=dt)
     out = torch.full_like(ref, 7.0)
     K.gather_gemm(K.CONV_S1, [x], w, n, [ref], (nb, hin - 1, hin - 1), ws, splitk=1)
-    for stag in (0, 1):
+    for stag in (0, 1, 2):
         out.fill_(7.0)
         rc = proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, stag, 0,
                                            torch.cuda.current_stream().cuda_stream)
@@ -38,10 +38,13 @@ for nb, hin, cin, n in ((2, 9, 64, 128), (3, 20, 128, 256), (16, 32, 256, 512)):
     flop = 2.0 * nb * (hin - 1) ** 2 * n * 16 * cin
     t_ref = timeit(lambda: K.gather_gemm(K.CONV_S1, [x], w, n, [ref], (nb, hin - 1, hin - 1), ws, splitk=1))
     ts = [timeit(lambda st=st: proto.pfa_proto_conv_s1_patch(x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, st, 0,
-                                                             torch.cuda.current_stream().cuda_stream)) for st in (0, 1)]
+                                                             torch.cuda.current_stream().cuda_stream)) for st in (0, 1, 2)]
     print(f"   product {t_ref:7.1f} us ({flop / t_ref / 1e6:5.0f} TF/s)   patch {ts[0]:7.1f} us ({flop / ts[0] / 1e6:5.0f} TF/s)"
-          f"   patch + staggered phases {ts[1]:7.1f} us ({flop / ts[1] / 1e6:5.0f} TF/s)")
+          f"   patch + staggered phases {ts[1]:7.1f} us ({flop / ts[1] / 1e6:5.0f} TF/s)"
+          f"   patch, 4 waves of 128x64 {ts[2]:7.1f} us ({flop / ts[2] / 1e6:5.0f} TF/s)")
     if nb == 16:      # ablations of the plain loop on the c4 shape (results are wrong when a bit is set)
         lab = {0: "full", 4: "-dma", 1: "-mfma", 2: "-ldsreads", 5: "-mfma,dma (reads only)", 6: "-reads,dma (mfma only)", 3: "-mfma,reads (dma only)", 7: "empty loop"}
         print("   ablations:", "  ".join(f"[{lab[d]}: " + "%.1f" % timeit(lambda d=d: proto.pfa_proto_conv_s1_patch(
             x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, 0, d, torch.cuda.current_stream().cuda_stream)) + "]" for d in lab))
+        print("   ablations, 4 waves:", "  ".join(f"[{lab[d]}: " + "%.1f" % timeit(lambda d=d: proto.pfa_proto_conv_s1_patch(
+            x.data_ptr(), w.data_ptr(), out.data_ptr(), nb, hin, hin, cin, n, 2, d, torch.cuda.current_stream().cuda_stream)) + "]" for d in lab))

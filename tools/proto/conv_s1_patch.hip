@@ -27,6 +27,11 @@ __device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+template <int OFF> __device__ __forceinline__ bf16x8 lds_read16o(unsigned addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
 template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
 
 struct ProtoK {
@@ -40,7 +45,10 @@ struct ProtoK {
 constexpr int TY = 8, TX = 32;                    // output patch of a workgroup: 256 pixels
 constexpr int PH = TY + 3, PW = TX + 3;           // input patch with halo
 constexpr int PSLOTS = PH * PW;                   // 385 pixels x 128 B
-constexpr int PPASS = 7;                          // 7 x 512 lanes x 16 B >= 385 x 128 B
+constexpr int PSTRIDE = 144;                      // 8-wave kernel: 128 B + one unused 16-byte piece per input pixel - 16
+                                                  // consecutive pixels then fall on 16 distinct bank groups for every chunk
+                                                  // WITHOUT an XOR swizzle, so a tap shift is a plain address offset
+constexpr int PPASS = 7;                          // 7 x 512 lanes x 16 B >= 385 x 144 B
 constexpr int PATCH_BYTES = PPASS * 512 * 16;     // 57,344 (padded: every lane of every pass writes)
 constexpr int W_BYTES = 128 * 128;                // 128 weight rows x 128 B
 constexpr int LDS_BYTES = 2 * PATCH_BYTES + 3 * W_BYTES;      // 163,840: the whole LDS of a CU
@@ -66,11 +74,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     unsigned pok = 0;
 #pragma unroll
     for (int j = 0; j < PPASS; ++j) {
-        const int q = j * 512 + tid, slot = q >> 3, cp = q & 7;
-        const int g = cp ^ ((slot >> 1) & 7);
+        const int q = j * 512 + tid, slot = q / 9, g = q - slot * 9;          // 9 pieces per pixel, the ninth unused
         const int py = slot / PW, px = slot - py * PW;
         const int iy = oy0 - 1 + py, ix = px - 1;
-        const bool ok = slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+        const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
         poff[j] = ok ? (unsigned)((((img * p.hin + iy) * p.win + ix) * p.cin + g * 8) * 2) : 0u;
         pok |= ok ? (1u << j) : 0u;
     }
@@ -102,9 +109,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     // fragment addressing: activation fragment b of this wave = 16 consecutive output pixels of patch row wm*2 + b/2
     const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-    int aslot[4];
+    unsigned abyte[4];                   // byte offset of this lane's piece of fragment b inside a patch buffer, tap (0,0), half 0
 #pragma unroll
-    for (int b = 0; b < 4; ++b) aslot[b] = (wm * 2 + (b >> 1)) * PW + (b & 1) * 16 + lrow;
+    for (int b = 0; b < 4; ++b) abyte[b] = ((wm * 2 + (b >> 1)) * PW + (b & 1) * 16 + lrow) * PSTRIDE + kk * 16;
     unsigned wfb[2];
     {
         const unsigned sw = (lrow >> 1) & 7;
@@ -119,19 +126,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     stage_w(0, 0);
     if (nsteps > 1) stage_w(1, 1);
     auto read_frags = [&](int i, bf16x8 (*wf)[4], bf16x8 (*af)[4]) {
+        // one VALU add per address register: the tap shift and the ring stage are wave-uniform offsets, the 16-row
+        // fragment pitch and the K half are immediates
         const int chunk = i >> 4, tap = i & 15;
-        const unsigned pbase = lds0 + (chunk & 1) * PATCH_BYTES;
-        const int tapslot = (tap >> 2) * PW + (tap & 3);
+        const unsigned tb = lds0 + (chunk & 1) * PATCH_BYTES + ((tap >> 2) * PW + (tap & 3)) * PSTRIDE;
+        const unsigned rb = (i % 3) * W_BYTES;
+        const unsigned w0 = wfb[0] + rb, w1 = wfb[1] + rb;
+        wf[0][0] = lds_read16o<0>(w0); wf[0][1] = lds_read16o<2048>(w0); wf[0][2] = lds_read16o<4096>(w0); wf[0][3] = lds_read16o<6144>(w0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int b = 0; b < 4; ++b) af[0][b] = lds_read16o<0>(abyte[b] + tb);
+        wf[1][0] = lds_read16o<0>(w1); wf[1][1] = lds_read16o<2048>(w1); wf[1][2] = lds_read16o<4096>(w1); wf[1][3] = lds_read16o<6144>(w1);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wf[h][a] = lds_read16(wfb[h] + (i % 3) * W_BYTES + a * 2048);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int slot = aslot[b] + tapslot;
-                af[h][b] = lds_read16(pbase + slot * 128 + (((kk + 4 * h) ^ ((slot >> 1) & 7)) << 4));
-            }
-        }
+        for (int b = 0; b < 4; ++b) af[1][b] = lds_read16o<64>(abyte[b] + tb);
     };
     auto mfma_half = [&](bf16x8 (*wf)[4], bf16x8 (*af)[4], int h) {
 #pragma unroll
@@ -215,6 +221,134 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Variant "big wave tile": the same 256 x 128 workgroup tile on FOUR waves (2 x 2), each 128 pixels x 64 channels: 128
+// accumulator registers, 12 fragment reads per 32 MFMAs instead of 8 per 16 (-25 % LDS read traffic).  One wave per SIMD
+// (up to 512 registers): both K halves of a step are read up front, so the second half's reads return under the first
+// half's 32 MFMAs.
+constexpr int PPASS4 = 13;                        // 13 x 256 lanes x 16 B >= 385 x 128 B
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void k_conv_s1_patch_w4(const ProtoK p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;                 // 2 x 2 waves, 128 x 64 per wave
+    const int lrow = lane & 15, kk = lane >> 4;
+    unsigned wid = blockIdx.x;
+    const int nt = wid % p.ntiles; wid /= p.ntiles;
+    const int ty = wid % p.tiles_y, img = wid / p.tiles_y;
+    const int oy0 = ty * TY, n0 = nt * 128;
+    const char* zero = (const char*)g_zero_page;
+
+    unsigned poff[PPASS4];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < PPASS4; ++j) {
+        const int q = j * 256 + tid, slot = q >> 3, cp = q & 7;
+        const int g = cp ^ ((slot >> 1) & 7);
+        const int py = slot / PW, px = slot - py * PW;
+        const int iy = oy0 - 1 + py, ix = px - 1;
+        const bool ok = slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
+        poff[j] = ok ? (unsigned)((((img * p.hin + iy) * p.win + ix) * p.cin + g * 8) * 2) : 0u;
+        pok |= ok ? (1u << j) : 0u;
+    }
+    auto stage_patch_piece = [&](int chunk, int j) {
+        const char* gp = ((pok >> j) & 1u) ? p.src + poff[j] + chunk * 128 : zero;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 256 + wave * 64) * 16), 16, 0, 0);
+    };
+    const int cs = tid & 7, r0 = tid >> 3;                   // 32 weight rows per pass, 4 passes
+    const int wg = cs ^ ((r0 >> 1) & 7);
+    unsigned woff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) woff[i] = (unsigned)(((n0 + r0 + 32 * i) * 16 * p.cin + wg * 8) * 2);
+    auto stage_w = [&](int step, int buf) {
+        const int chunk = step >> 4, tap = step & 15;
+        char* wb = smem + 2 * PATCH_BYTES + buf * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* gp = p.w + woff[i] + (tap * p.cin + chunk * 64) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    int aslot[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) aslot[b] = (wm * 4 + (b >> 1)) * PW + (b & 1) * 16 + lrow;
+    unsigned wfb[2];
+    {
+        const unsigned sw = (lrow >> 1) & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wfb[h] = lds0 + 2 * PATCH_BYTES + (wn * 64 + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
+    }
+    const int nchunks = p.cin / 64, nsteps = nchunks * 16;
+#pragma unroll
+    for (int j = 0; j < PPASS4; ++j) stage_patch_piece(0, j);
+    stage_w(0, 0);
+    if (nsteps > 1) stage_w(1, 1);
+    bf16x8 wf[2][4], af[2][8];
+    bool prev_patch_piece = false;
+    for (int i = 0; i < nsteps; ++i) {
+        const int chunk = i >> 4, tap = i & 15;
+        if (i + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (prev_patch_piece) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        prev_patch_piece = tap < PPASS4 && chunk + 1 < nchunks && !(p.dbg & 4);
+        if (prev_patch_piece) stage_patch_piece(chunk + 1, tap);
+        if (i + 2 < nsteps && !(p.dbg & 4)) stage_w(i + 2, (i + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.dbg & 2) || i == 0) {
+            const unsigned pbase = lds0 + (chunk & 1) * PATCH_BYTES;
+            const int tapslot = (tap >> 2) * PW + (tap & 3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) wf[h][a] = lds_read16(wfb[h] + (i % 3) * W_BYTES + a * 2048);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int slot = aslot[b] + tapslot;
+                    af[h][b] = lds_read16(pbase + slot * 128 + (((kk + 4 * h) ^ ((slot >> 1) & 7)) << 4));
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 0) WAIT_LGKM(12); else WAIT_LGKM(0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pin(wf[h][a]);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) pin(af[h][b]);
+            if (!(p.dbg & 1)) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][a], af[h][b], acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int oy = oy0 + wm * 4 + (b >> 1), ox = (b & 1) * 16 + lrow;
+        if (oy >= p.hout || ox >= p.wout) continue;
+        char* orow = p.out + ((size_t)((img * p.hout + oy) * p.wout + ox) * p.n) * 2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int col = n0 + wn * 64 + a * 16 + 4 * kk;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[a][b][r];
+            *(bf16x4*)(orow + col * 2) = o;
+        }
+    }
+}
+
 // src [nb][hin][win][cin] bf16, w [n][16][cin] bf16, out [nb][hin-1][win-1][n] bf16; cin % 64 == 0, n % 128 == 0, win - 1 <= 32
 extern "C" int pfa_proto_conv_s1_patch(const void* src, const void* w, void* out, int nb, int hin, int win, int cin, int n,
                                        int staggered, int dbg, void* stream) {
@@ -230,6 +364,15 @@ extern "C" int pfa_proto_conv_s1_patch(const void* src, const void* w, void* out
         attr_done = true;
     }
     const dim3 grid(nb * k.tiles_y * k.ntiles);
+    if (staggered == 2) {            // the 4-wave variant with 128 x 64 per-wave tiles
+        static bool attr4 = false;
+        if (!attr4) {
+            (void)hipFuncSetAttribute((const void*)k_conv_s1_patch_w4, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr4 = true;
+        }
+        hipLaunchKernelGGL(k_conv_s1_patch_w4, grid, dim3(256), LDS_BYTES, (hipStream_t)stream, k);
+        return (int)hipGetLastError();
+    }
     if (staggered) hipLaunchKernelGGL(k_conv_s1_patch<true>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, k);
     else hipLaunchKernelGGL(k_conv_s1_patch<false>, grid, dim3(512), LDS_BYTES, (hipStream_t)stream, k);
     return (int)hipGetLastError();
