@@ -40,10 +40,14 @@ __device__ __forceinline__ float row_sum16(float v) {      // sum over a DPP row
 struct PatchK {
     const char* src;     // [nb][hin][win][cin] bf16
     const char* w;       // [n][16][cin] bf16
-    char* out;           // [nb][hout][wout][n] bf16
-    float* psum;         // optional [nb * tiles_y][n] partial sums / sums of squares
+    char* out;           // [nb][hout][wout][n] bf16 (splitk == 1)
+    float* slab;         // splitk > 1: float32 [splitk][nb*hout*wout][n] partial sums for the finish pass
+    float* psum;         // optional [nb * tiles_y][n] partial sums / sums of squares (splitk == 1)
     float* psq;
     int nb, hin, win, cin, n, hout, wout, tiles_y, ntiles, nwg;
+    int org;             // patch origin = output position - org: 1 = forward (pad 1), 2 = input gradient (pad 2, taps reversed)
+    int flip;            // input gradient: patch offset k reads weight tap 15 - k
+    int splitk, cper;    // K slices over the channel chunks, chunks per slice
 };
 
 constexpr int TY = 8, TX = 32;                    // output patch of a workgroup: 256 pixels
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int lrow = lane & 15, kk = lane >> 4;
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);             // an XCD takes a contiguous run: the n-tiles of a patch together
     const int nt = wid % p.ntiles; wid /= p.ntiles;
+    const int split = wid % p.splitk; wid /= p.splitk;
     const int ty = wid % p.tiles_y, img = wid / p.tiles_y;
     const int oy0 = ty * TY, n0 = nt * 128;
     const char* zero = (const char*)g_pfa_zero_page;
@@ -74,13 +79,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int j = 0; j < PPASS; ++j) {
         const int q = j * 512 + tid, slot = q / 9, g = q - slot * 9;
         const int py = slot / PW, px = slot - py * PW;
-        const int iy = oy0 - 1 + py, ix = px - 1;
+        const int iy = oy0 - p.org + py, ix = px - p.org;
         const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
         poff[j] = ok ? (unsigned)((((img * p.hin + iy) * p.win + ix) * p.cin + g * 8) * 2) : 0u;
         pok |= ok ? (1u << j) : 0u;
     }
-    auto stage_patch_piece = [&](int chunk, int j) {
-        const char* gp = ((pok >> j) & 1u) ? p.src + poff[j] + chunk * 128 : zero;
+    const int c0 = split * p.cper;                           // first channel chunk of this K slice
+    auto stage_patch_piece = [&](int chunk, int j) {         // chunk: index inside the slice (selects the LDS buffer)
+        const char* gp = ((pok >> j) & 1u) ? p.src + poff[j] + (c0 + chunk) * 128 : zero;
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
     };
     // ---- weight staging: 2 pieces per step (rows r0 + 64 i), chunk slot cs holds source chunk cs ^ swz(row)
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * p.cin + wg * 8) * 2);
     auto stage_w = [&](int step, int buf) {                 // step = chunk * 16 + tap
-        const int chunk = step >> 4, tap = step & 15;
+        const int chunk = c0 + (step >> 4), tap = p.flip ? 15 - (step & 15) : (step & 15);
         char* wb = smem + 2 * PATCH_BYTES + buf * W_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         for (int h = 0; h < 2; ++h) wfb[h] = lds0 + 2 * PATCH_BYTES + (wn * 64 + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
     }
 
-    const int nchunks = p.cin / 64, nsteps = nchunks * 16;
+    const int nchunks = p.cper, nsteps = nchunks * 16;
 #pragma unroll
     for (int j = 0; j < PPASS; ++j) stage_patch_piece(0, j);
     stage_w(0, 0);
@@ -189,6 +195,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         valid[b] = oy < p.hout && ox < p.wout;
         opix[b] = valid[b] ? (size_t)(img * p.hout + oy) * p.wout + ox : 0;
     }
+    if (p.splitk > 1) {                                    // partial sums for the finish pass (rows = output pixels)
+        const size_t npix = (size_t)p.nb * p.hout * p.wout;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (!valid[b]) continue;
+            float* srow = p.slab + ((size_t)split * npix + opix[b]) * p.n;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) *(f32x4*)(srow + n0 + wn * 64 + a * 16 + 4 * kk) = acc[a][b];
+        }
+        return;
+    }
     if (p.psum) {
         __syncthreads();                                   // every wave is done with the staging buffers
         float* red = (float*)smem;                         // [2][4 wm][128]
@@ -234,21 +251,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 
 }  // namespace
 
-// Geometry the patch kernel is built for (the caller has already checked: PFA_CONV_S1, bf16, one source, one unpadded
-// output, no bias / activation / fused epilogue, no K slices).
-bool pfa_conv_s1_patch_ok(int nb, int hin, int win, int cin, int n, int* stat_tiles) {
-    if (cin % 64 || n % 128 || win - 1 > TX || hin < 2 || win < 2) return false;
-    if (stat_tiles) *stat_tiles = nb * ((hin - 1 + TY - 1) / TY);
+// Geometry the patch kernel is built for (the caller has already checked: bf16, one source, one unpadded output, no bias /
+// activation).  grad = 0: PFA_CONV_S1 forward (output hin-1 x win-1); grad = 1: PFA_CONV_S1_DGRAD (output hin+1 x win+1).
+bool pfa_conv_s1_patch_ok(int grad, int nb, int hin, int win, int cin, int n, int splitk, int* stat_tiles) {
+    const int hout = grad ? hin + 1 : hin - 1, wout = grad ? win + 1 : win - 1;
+    if (cin % 64 || n % 128 || wout > TX || hout < 1 || wout < 1 || splitk < 1 || (cin / 64) % splitk) return false;
+    if (stat_tiles) *stat_tiles = nb * ((hout + TY - 1) / TY);
     return true;
 }
 
-int pfa_conv_s1_patch(const void* src, const void* w, void* out, float* psum, float* psq, int nb, int hin, int win,
-                      int cin, int n, hipStream_t st) {
+int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float* slab, int splitk, float* psum, float* psq,
+                      int nb, int hin, int win, int cin, int n, hipStream_t st) {
     PatchK k;
-    k.src = (const char*)src; k.w = (const char*)w; k.out = (char*)out; k.psum = psum; k.psq = psq;
-    k.nb = nb; k.hin = hin; k.win = win; k.cin = cin; k.n = n; k.hout = hin - 1; k.wout = win - 1;
+    k.src = (const char*)src; k.w = (const char*)w; k.out = (char*)out; k.slab = slab; k.psum = psum; k.psq = psq;
+    k.nb = nb; k.hin = hin; k.win = win; k.cin = cin; k.n = n;
+    k.hout = grad ? hin + 1 : hin - 1; k.wout = grad ? win + 1 : win - 1;
+    k.org = grad ? 2 : 1; k.flip = grad ? 1 : 0;
+    k.splitk = splitk; k.cper = cin / 64 / splitk;
     k.tiles_y = (k.hout + TY - 1) / TY; k.ntiles = n / 128;
-    k.nwg = nb * k.tiles_y * k.ntiles;
+    k.nwg = nb * k.tiles_y * k.ntiles * splitk;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_s1_patch, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

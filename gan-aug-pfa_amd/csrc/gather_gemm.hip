@@ -1264,17 +1264,20 @@ inline int fill_params_geometry(const pfa_gather_args* a, GatherK& k, int& class
     return fill_params(&b, k, classes);
 }
 
-// Launches that take the patch kernel of conv_patch.hip instead of the implicit GEMM: stride-1 forward convolutions in bf16
-// with one source and one unpadded output, nothing fused, no K slices, at least 128 workgroups (smaller launches rely on K
-// slices).  pfa_set_knob(3, 1) turns the route off, 2 takes it whenever the geometry fits (tests).
+// Launches that take the patch kernel of conv_patch.hip instead of the implicit GEMM: stride-1 convolutions (forward, and
+// input gradient = the same walk with the taps reversed) in bf16 with one source and one unpadded output, no bias /
+// activation, at least 128 workgroups (smaller launches rely on more K slices than the channel chunks give).  A fused
+// epilogue rides on the finish pass, i.e. needs a K-sliced launch.  pfa_set_knob(3, 1) turns the route off, 2 takes it
+// whenever the geometry fits (tests).
 inline bool patch_route(const pfa_gather_args* a, const GatherK& k, int* tiles) {
     if (g_knob[3] == 1) return false;
-    if (!(a->mode == PFA_CONV_S1 && a->dtype == PFA_BF16 && a->c2 == 0 && a->bias == nullptr && a->act == PFA_ACT_NONE &&
-          a->fuse_out == 0 && k.splitk == 1 && a->n1 >= a->n && a->ld1 == a->n && a->ld2 == 0))
+    const bool fwd = a->mode == PFA_CONV_S1, grad = a->mode == PFA_CONV_S1_DGRAD;
+    if (!((fwd || grad) && a->dtype == PFA_BF16 && a->c2 == 0 && a->bias == nullptr && a->act == PFA_ACT_NONE &&
+          a->n1 >= a->n && a->ld1 == a->n && a->ld2 == 0 && (a->fuse_out == 0 || (a->fuse_out != 3 && k.splitk > 1))))
         return false;
     int t = 0;
-    if (!pfa_conv_s1_patch_ok(a->nb, a->hs, a->ws, a->c1, a->n, &t)) return false;
-    if (g_knob[3] != 2 && (long long)t * (a->n / 128) < 128) return false;
+    if (!pfa_conv_s1_patch_ok(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &t)) return false;
+    if (g_knob[3] != 2 && (long long)t * (a->n / 128) * k.splitk < 128) return false;
     if (tiles) *tiles = t;
     return true;
 }
@@ -1292,7 +1295,7 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
     int ptiles = 0;
-    if (patch_route(a, k, &ptiles)) return ptiles;
+    if (k.splitk == 1 && patch_route(a, k, &ptiles)) return ptiles;
     if (k.splitk > 1) {
         const int rpb = finish_rows_per_block(k.n, k.n1, k.ld1, k.act, k.npix);
         return (k.npix + rpb - 1) / rpb;
@@ -1473,29 +1476,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
                 "pfa_gather_gemm: a fused BatchNorm backward needs psum/psq, a fused activation backward must not pass them");
     hipStream_t st = (hipStream_t)s;
     int ptiles = 0;
-    if (patch_route(a, k, &ptiles)) {
-        TimedLaunch pt{};
-        const bool ptiming = g_timing;
-        if (ptiming) {
-            (void)hipEventCreate(&pt.e0);
-            (void)hipEventCreate(&pt.e1);
-            (void)hipEventRecord(pt.e0, st);
-        }
-        const int prc = pfa_conv_s1_patch(a->src1, a->w, a->out1, a->psum, a->psq, a->nb, a->hs, a->ws, a->c1, a->n, st);
-        g_last_gather_name = "k_conv_s1_patch<bf16,8x32,128>";
-        if (ptiming) {
-            (void)hipEventRecord(pt.e1, st);
-            pt.name = g_last_gather_name;
-            pt.splitk = 1;
-            pt.flop = 2.0 * (double)k.M * k.n * 16.0 * k.ctot;
-            pt.bytes = 2.0 * ((double)a->nb * a->hs * a->ws * k.ctot + (double)k.n * 16.0 * k.ctot + (double)k.npix * a->ld1);
-            std::lock_guard<std::mutex> lk(g_timed_mu);
-            g_timed.push_back(pt);
-        }
-        if (prc) return prc;
-        a->ntiles_stat = ptiles;
-        return 0;
-    }
+    const bool patch = patch_route(a, k, &ptiles);
     const TileCfg cfg = choose_cfg(k);
     int rc;
     GatherK kk = k;
@@ -1507,8 +1488,14 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         (void)hipEventCreate(&tl.e1);
         (void)hipEventRecord(tl.e0, st);
     }
-    rc = a->dtype == PFA_BF16 ? dispatch_gather<bf16_t>(kk, classes, cfg.id, st)
-                              : dispatch_gather<float>(kk, classes, cfg.id, st);
+    if (patch) {
+        rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
+                               a->nb, a->hs, a->ws, a->c1, a->n, st);
+        g_last_gather_name = "k_conv_s1_patch<bf16,8x32,128>";
+    } else {
+        rc = a->dtype == PFA_BF16 ? dispatch_gather<bf16_t>(kk, classes, cfg.id, st)
+                                  : dispatch_gather<float>(kk, classes, cfg.id, st);
+    }
     if (timing) {
         (void)hipEventRecord(tl.e1, st);
         const double es = a->dtype == PFA_BF16 ? 2.0 : 4.0, taps = a->mode == PFA_TCONV_S2 ? 4.0 : 16.0;
@@ -1540,7 +1527,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         if (rc) return rc;
         a->ntiles_stat = tiles;
     } else {
-        a->ntiles_stat = classes * ((k.M + cfg.bm - 1) / cfg.bm);
+        a->ntiles_stat = patch ? ptiles : classes * ((k.M + cfg.bm - 1) / cfg.bm);
     }
     return 0;
 }

@@ -42,9 +42,9 @@ extern std::atomic<uint64_t> g_pfa_launches;
     } while (0)
 
 // csrc/conv_patch.hip: stride-1 convolution forward with the input patch kept in LDS (dispatched by pfa_gather_gemm)
-bool pfa_conv_s1_patch_ok(int nb, int hin, int win, int cin, int n, int* stat_tiles);
-int pfa_conv_s1_patch(const void* src, const void* w, void* out, float* psum, float* psq, int nb, int hin, int win, int cin,
-                      int n, hipStream_t st);
+bool pfa_conv_s1_patch_ok(int grad, int nb, int hin, int win, int cin, int n, int splitk, int* stat_tiles);
+int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float* slab, int splitk, float* psum, float* psq,
+                      int nb, int hin, int win, int cin, int n, hipStream_t st);
 
 static inline int pfa_ch(int dtype) { return dtype == PFA_BF16 ? 8 : 4; }
 static inline int pfa_esize(int dtype) { return dtype == PFA_BF16 ? 2 : 4; }

@@ -104,11 +104,12 @@ def test_conv_forward(case, dtype, ws):
     close(q, (raw.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
 
 
-PATCH_CASES = [  # name, N, Ci, H, W, Co
-    ("c4_like", 2, 64, 17, 19, 128),          # ragged patch rows (16 -> two 8-row tiles) and columns (18 of 32)
-    ("full_width", 3, 128, 12, 33, 256),      # 32 output columns: the whole patch width; two channel chunks, two n-tiles
-    ("one_row", 1, 256, 2, 5, 128),           # a single output row
-    ("tall", 1, 64, 40, 9, 128),              # five row tiles, the last one ragged
+PATCH_CASES = [  # name, N, Ci, H, W, Co, K slices
+    ("c4_like", 2, 64, 17, 19, 128, 1),       # ragged patch rows (16 -> two 8-row tiles) and columns (18 of 32)
+    ("full_width", 3, 128, 12, 33, 256, 1),   # 32 output columns: the whole patch width; two channel chunks, two n-tiles
+    ("one_row", 1, 256, 2, 5, 128, 1),        # a single output row
+    ("tall", 1, 64, 40, 9, 128, 1),           # five row tiles, the last one ragged
+    ("sliced", 2, 256, 10, 13, 128, 2),       # two K slices of two channel chunks each -> slab + finish pass
 ]
 
 
@@ -117,7 +118,7 @@ def test_conv_s1_patch_kernel(case, ws):
     """Stride-1 forward convolutions (the discriminator's c4) take the patch kernel of conv_patch.hip when they are large
     enough; pfa_set_knob(3, 2) routes these small ones there too.  Same oracle, same statistics contract as the
     implicit GEMM, and the implicit GEMM's result up to the order of the float32 sums."""
-    name, n, ci, h, w, co = case
+    name, n, ci, h, w, co, slices = case
     dtype = torch.bfloat16
     x = rnd(fill.uniform(name + ".px", (n, ci, h, w)), dtype)
     wt = rnd(fill.uniform(name + ".pw", (co, ci, 4, 4), -0.25, 0.25), dtype)
@@ -130,7 +131,8 @@ def test_conv_s1_patch_kernel(case, ws):
         out = torch.full((n, ho, wo, co), 7.0, dtype=dtype, device="cuda")
         lib.pfa_set_knob(3, knob)
         try:
-            psum, psq, nt = K.gather_gemm(K.CONV_S1, [to_nhwc(x, dtype)], same, co, [out], (n, ho, wo), ws, stats=True, splitk=1)
+            psum, psq, nt = K.gather_gemm(K.CONV_S1, [to_nhwc(x, dtype)], same, co, [out], (n, ho, wo), ws, stats=True,
+                                          splitk=slices)
             kernel = lib.pfa_last_gather_kernel().decode()
         finally:
             lib.pfa_set_knob(3, 0)
@@ -142,6 +144,40 @@ def test_conv_s1_patch_kernel(case, ws):
     close(from_nhwc(outs[0], co), from_nhwc(outs[1], co), dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
     close(stats[0][0], want.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum", scale=np.abs(want).sum(axis=(0, 2, 3)).max())
     close(stats[0][1], (want.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
+
+
+PATCH_GRAD_CASES = [  # name, N, Ci (columns of the result), H, W, Co (contraction), K slices
+    ("c4_grad_like", 2, 128, 17, 19, 64, 1),
+    ("full_width", 2, 128, 12, 32, 128, 2),     # 32 result columns; two K slices
+    ("c4_grad_sliced", 3, 256, 9, 8, 256, 4),
+]
+
+
+@pytest.mark.parametrize("case", PATCH_GRAD_CASES, ids=[c[0] for c in PATCH_GRAD_CASES])
+def test_conv_s1_patch_kernel_input_gradient(case, ws):
+    """The input gradient of a stride-1 convolution on the patch kernel: the same walk over the (pad 2) patch with the taps
+    reversed; K slices go through the slab + finish pass."""
+    name, n, ci, h, w, co, slices = case
+    dtype = torch.bfloat16
+    x = fill.uniform(name + ".gx", (n, ci, h, w))
+    wt = rnd(fill.uniform(name + ".gw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    dy = rnd(fill.uniform(name + ".gdy", (n, co, h - 1, w - 1)), dtype)
+    want, _, _ = ops.conv2d_bwd(x, wt, dy, 1)
+    _, tr = shadows(wt, dtype, want=("tr",))
+    lib = _lib.lib()
+    outs = []
+    for knob in (2, 1):
+        out = torch.full((n, h, w, ci), 7.0, dtype=dtype, device="cuda")
+        lib.pfa_set_knob(3, knob)
+        try:
+            K.gather_gemm(K.CONV_S1_DGRAD, [to_nhwc(dy, dtype)], tr, ci, [out], (n, h, w), ws, splitk=slices)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(3, 0)
+        assert kernel.startswith("k_conv_s1_patch") == (knob == 2), kernel
+        outs.append(out)
+    close(from_nhwc(outs[0], ci), want, dtype, name)
+    close(from_nhwc(outs[0], ci), from_nhwc(outs[1], ci), dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
 
 
 CONVT_FWD = [  # name, N, cin parts, H, W, Co, bias, act, splitk
