@@ -2,7 +2,7 @@
 //
 // pfa_gather_gemm stages, for every (tap, channel chunk) K-step, one 128-byte piece per output pixel: with stride 1 the 16
 // taps re-fetch the same input pixels 16 times and the K-loop is bound by the L2->LDS instruction rate.
-// Here a workgroup owns an 8 x 32 patch of output pixels of one image and 128 output channels.  It stages the
+// Here a workgroup owns an 8 x 32 patch of output pixels of one image (wider maps are tiled in x too) and 128 output channels.  It stages the
 // (8+3) x (32+3) input pixels of a 64-channel chunk ONCE - double-buffered, 7 DMA pieces per wave and chunk, one per tap
 // step of the previous chunk - and walks the 16 taps inside LDS; only the weight tile (128 rows x 128 B per step, 2 pieces)
 // streams through a 3-stage ring with a counted vmcnt.  DMA instructions per K-step and wave: 2.4 instead of 6.
@@ -42,9 +42,9 @@ struct PatchK {
     const char* w;       // [n][16][cin] bf16
     char* out;           // [nb][hout][wout][n] bf16 (splitk == 1)
     float* slab;         // splitk > 1: float32 [splitk][nb*hout*wout][n] partial sums for the finish pass
-    float* psum;         // optional [nb * tiles_y][n] partial sums / sums of squares (splitk == 1)
+    float* psum;         // optional [nb * tiles_y * tiles_x][n] partial sums / sums of squares (splitk == 1)
     float* psq;
-    int nb, hin, win, cin, n, hout, wout, tiles_y, ntiles, nwg;
+    int nb, hin, win, cin, n, hout, wout, tiles_y, tiles_x, ntiles, nwg;
     int org;             // patch origin = output position - org: 1 = forward (pad 1), 2 = input gradient (pad 2, taps reversed)
     int flip;            // input gradient: patch offset k reads weight tap 15 - k
     int splitk, cper;    // K slices over the channel chunks, chunks per slice
@@ -68,8 +68,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);             // an XCD takes a contiguous run: the n-tiles of a patch together
     const int nt = wid % p.ntiles; wid /= p.ntiles;
     const int split = wid % p.splitk; wid /= p.splitk;
+    const int tx = wid % p.tiles_x; wid /= p.tiles_x;
     const int ty = wid % p.tiles_y, img = wid / p.tiles_y;
-    const int oy0 = ty * TY, n0 = nt * 128;
+    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
     const char* zero = (const char*)g_pfa_zero_page;
 
     // ---- patch staging: this lane's 7 pieces (9 pieces per pixel, the ninth unused)
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     for (int j = 0; j < PPASS; ++j) {
         const int q = j * 512 + tid, slot = q / 9, g = q - slot * 9;
         const int py = slot / PW, px = slot - py * PW;
-        const int iy = oy0 - p.org + py, ix = px - p.org;
+        const int iy = oy0 - p.org + py, ix = ox0 - p.org + px;
         const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)p.hin && (unsigned)ix < (unsigned)p.win;
         poff[j] = ok ? (unsigned)((((img * p.hin + iy) * p.win + ix) * p.cin + g * 8) * 2) : 0u;
         pok |= ok ? (1u << j) : 0u;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     size_t opix[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const int oy = oy0 + wm * 2 + (b >> 1), ox = (b & 1) * 16 + lrow;
+        const int oy = oy0 + wm * 2 + (b >> 1), ox = ox0 + (b & 1) * 16 + lrow;
         valid[b] = oy < p.hout && ox < p.wout;
         opix[b] = valid[b] ? (size_t)(img * p.hout + oy) * p.wout + ox : 0;
     }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { s += red[i * 128 + tid]; q += red[(4 + i) * 128 + tid]; }
-            const size_t trow = (size_t)img * p.tiles_y + ty;
+            const size_t trow = ((size_t)img * p.tiles_y + ty) * p.tiles_x + tx;
             p.psum[trow * p.n + n0 + tid] = s;
             p.psq[trow * p.n + n0 + tid] = q;
         }
@@ -255,8 +256,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 // activation).  grad = 0: PFA_CONV_S1 forward (output hin-1 x win-1); grad = 1: PFA_CONV_S1_DGRAD (output hin+1 x win+1).
 bool pfa_conv_s1_patch_ok(int grad, int nb, int hin, int win, int cin, int n, int splitk, int* stat_tiles) {
     const int hout = grad ? hin + 1 : hin - 1, wout = grad ? win + 1 : win - 1;
-    if (cin % 64 || n % 128 || wout > TX || hout < 1 || wout < 1 || splitk < 1 || (cin / 64) % splitk) return false;
-    if (stat_tiles) *stat_tiles = nb * ((hout + TY - 1) / TY);
+    if (cin % 64 || n % 128 || hout < 1 || wout < 1 || splitk < 1 || (cin / 64) % splitk) return false;
+    if (stat_tiles) *stat_tiles = nb * ((hout + TY - 1) / TY) * ((wout + TX - 1) / TX);
     return true;
 }
 
@@ -268,8 +269,8 @@ int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float
     k.hout = grad ? hin + 1 : hin - 1; k.wout = grad ? win + 1 : win - 1;
     k.org = grad ? 2 : 1; k.flip = grad ? 1 : 0;
     k.splitk = splitk; k.cper = cin / 64 / splitk;
-    k.tiles_y = (k.hout + TY - 1) / TY; k.ntiles = n / 128;
-    k.nwg = nb * k.tiles_y * k.ntiles * splitk;
+    k.tiles_y = (k.hout + TY - 1) / TY; k.tiles_x = (k.wout + TX - 1) / TX; k.ntiles = n / 128;
+    k.nwg = nb * k.tiles_y * k.tiles_x * k.ntiles * splitk;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_s1_patch, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -110,6 +110,7 @@ PATCH_CASES = [  # name, N, Ci, H, W, Co, K slices
     ("one_row", 1, 256, 2, 5, 128, 1),        # a single output row
     ("tall", 1, 64, 40, 9, 128, 1),           # five row tiles, the last one ragged
     ("sliced", 2, 256, 10, 13, 128, 2),       # two K slices of two channel chunks each -> slab + finish pass
+    ("wide", 1, 64, 11, 71, 128, 1),          # 70 output columns: three patch columns, the last one ragged (512x512 inputs)
 ]
 
 
@@ -150,6 +151,7 @@ PATCH_GRAD_CASES = [  # name, N, Ci (columns of the result), H, W, Co (contracti
     ("c4_grad_like", 2, 128, 17, 19, 64, 1),
     ("full_width", 2, 128, 12, 32, 128, 2),     # 32 result columns; two K slices
     ("c4_grad_sliced", 3, 256, 9, 8, 256, 4),
+    ("wide", 1, 128, 10, 40, 64, 1),            # 40 result columns: two patch columns
 ]
 
 
