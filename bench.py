@@ -91,12 +91,17 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
         if t.get("kernel") == kernel:
             traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather_ring.json"
     total_ms = sum(v[0] for v in per.values())
+    # every MFMA convolution kernel of the step, largest time first (the fields above `kernels` describe the first one)
+    others = [dict(kernel=k, launches_per_step=v[3] // steps, avg_launch_us=round(1e3 * v[0] / v[3], 2),
+                   achieved=round(v[1] / (v[0] * 1e-3) / 1e12, 2), frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4),
+                   share_of_implicit_gemm_time=round(v[0] / total_ms, 3))
+              for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])]
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                 traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(tbytes / n),
                 kernel=kernel, launches_per_step=n // steps, split_k_launches_per_step=nsplit // steps,
                 avg_launch_us=round(1e3 * tms / n, 2), flop_per_launch=round(tflop / n),
                 flop_share_of_step=round(tflop / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3),
-                share_of_implicit_gemm_time=round(tms / total_ms, 3))
+                share_of_implicit_gemm_time=round(tms / total_ms, 3), kernels=others)
 
 
 def cpu_baseline(size, steps):
