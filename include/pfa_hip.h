@@ -58,7 +58,7 @@ uint64_t pfa_launch_count(void);
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
  * 5 = no K-group pairs, 6 = pairs from four slices on);
- * id 3: stride-1 forward convolutions on the input-patch kernel (conv_patch.hip): 0 = launches with >= 128 workgroups,
+ * id 3: stride-1 convolutions (forward and input gradient) on the input-patch kernel (conv_patch.hip): 0 = launches with >= 128 workgroups,
  * 1 = never, 2 = whenever the geometry fits;
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
