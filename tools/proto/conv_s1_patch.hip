@@ -349,6 +349,171 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1))) void k
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Transposed conv (k4, s2, p1) = the product's PFA_TCONV_S2 (also the input gradient of a stride-2 conv): one output parity
+// class (py, px) per workgroup, 8 x 32 source-grid positions, (8+1) x (32+1) input patch per 64-channel chunk, FOUR tap
+// steps per chunk.  The 6 patch pieces of the next chunk go out in the first two steps of the current one (3 + 3), so that
+// the wait of the third step has retired them before the chunk changes.  Staggered phases, 144-byte patch pixels.
+struct ProtoT {
+    const char* src;     // [nb][h][w][cin] bf16
+    const char* w;       // [n][16][cin] bf16 (the product's "tr" layout: row = output channel)
+    char* out;           // [nb][2h][2w][n] bf16
+    int nb, h, w_, cin, n, tiles_y, tiles_x, ntiles;
+};
+constexpr int TPH = TY + 1, TPW = TX + 1, TPSLOTS = TPH * TPW;        // 9 x 33 = 297 pixels
+constexpr int TPPASS = 6;                                               // 6 x 512 x 16 B >= 297 x 144 B
+constexpr int TPATCH_BYTES = TPPASS * 512 * 16;                         // 49,152
+constexpr int TLDS_BYTES = 2 * TPATCH_BYTES + 3 * W_BYTES;              // 147,456
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_tconv_patch(const ProtoT p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int lrow = lane & 15, kk = lane >> 4;
+    unsigned wid = blockIdx.x;
+    const int nt = wid % p.ntiles; wid /= p.ntiles;
+    const int cls = wid & 3; wid >>= 2;
+    const int tx = wid % p.tiles_x; wid /= p.tiles_x;
+    const int ty = wid % p.tiles_y, img = wid / p.tiles_y;
+    const int py = cls >> 1, px = cls & 1;
+    const int qy0 = ty * TY, qx0 = tx * TX, n0 = nt * 128;
+    const char* zero = (const char*)g_zero_page;
+
+    unsigned poff[TPPASS];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < TPPASS; ++j) {
+        const int q = j * 512 + tid, slot = q / 9, g = q - slot * 9;
+        const int sy = slot / TPW, sx = slot - sy * TPW;
+        const int iy = qy0 + py - 1 + sy, ix = qx0 + px - 1 + sx;
+        const bool ok = g < 8 && slot < TPSLOTS && (unsigned)iy < (unsigned)p.h && (unsigned)ix < (unsigned)p.w_;
+        poff[j] = ok ? (unsigned)((((img * p.h + iy) * p.w_ + ix) * p.cin + g * 8) * 2) : 0u;
+        pok |= ok ? (1u << j) : 0u;
+    }
+    auto stage_patch_piece = [&](int chunk, int j) {
+        const char* gp = ((pok >> j) & 1u) ? p.src + poff[j] + chunk * 128 : zero;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * TPATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    const int cs = tid & 7, r0 = tid >> 3;
+    const int wg = cs ^ ((r0 >> 1) & 7);
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * p.cin + wg * 8) * 2);
+    auto stage_w = [&](int step, int buf) {                 // step = chunk * 4 + tap
+        const int chunk = step >> 2, t = step & 3;
+        const int widx = (1 - py + 2 * (t >> 1)) * 4 + (1 - px + 2 * (t & 1));
+        char* wb = smem + 2 * TPATCH_BYTES + buf * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* gp = p.w + woff[i] + (widx * p.cin + chunk * 64) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    unsigned abyte[4];       // position q = (row wm*2 + b/2, col (b&1)*16 + lrow); tap (ty,tx) reads patch (row + 1 - ty, col + 1 - tx)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) abyte[b] = ((wm * 2 + (b >> 1)) * TPW + (b & 1) * 16 + lrow) * PSTRIDE + kk * 16;
+    unsigned wfb[2];
+    {
+        const unsigned sw = (lrow >> 1) & 7;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wfb[h] = lds0 + 2 * TPATCH_BYTES + (wn * 64 + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
+    }
+    const int nchunks = p.cin / 64, nsteps = nchunks * 4;
+#pragma unroll
+    for (int j = 0; j < TPPASS; ++j) stage_patch_piece(0, j);
+    stage_w(0, 0);
+    stage_w(1, 1);
+    bf16x8 wf[2][4], af[2][4];
+    const bool late = wave >= 4;
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nsteps; ++i) {
+        const int chunk = i >> 2, t = i & 3;
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned tb = lds0 + (chunk & 1) * TPATCH_BYTES + ((1 - (t >> 1)) * TPW + (1 - (t & 1))) * PSTRIDE;
+            const unsigned rb = (i % 3) * W_BYTES;
+            const unsigned w0 = wfb[0] + rb, w1 = wfb[1] + rb;
+            wf[0][0] = lds_read16o<0>(w0); wf[0][1] = lds_read16o<2048>(w0); wf[0][2] = lds_read16o<4096>(w0); wf[0][3] = lds_read16o<6144>(w0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) af[0][b] = lds_read16o<0>(abyte[b] + tb);
+            wf[1][0] = lds_read16o<0>(w1); wf[1][1] = lds_read16o<2048>(w1); wf[1][2] = lds_read16o<4096>(w1); wf[1][3] = lds_read16o<6144>(w1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) af[1][b] = lds_read16o<64>(abyte[b] + tb);
+        }
+        const bool pp = t < 2 && chunk + 1 < nchunks;        // 3 patch pieces of the next chunk in each of the first two steps
+        if (pp) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) stage_patch_piece(chunk + 1, t * 3 + j);
+        }
+        if (i + 2 < nsteps) {
+            stage_w(i + 2, (i + 2) % 3);
+            if (pp) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        WAIT_LGKM(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) pin(wf[h][a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) pin(af[h][b]);
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][a], af[h][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int qy = qy0 + wm * 2 + (b >> 1), qx = qx0 + (b & 1) * 16 + lrow;
+        if (qy >= p.h || qx >= p.w_) continue;
+        char* orow = p.out + ((size_t)((img * 2 * p.h + 2 * qy + py) * 2 * p.w_ + 2 * qx + px) * p.n) * 2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int col = n0 + wn * 64 + a * 16 + 4 * kk;
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)acc[a][b][r];
+            *(bf16x4*)(orow + col * 2) = o;
+        }
+    }
+}
+
+extern "C" int pfa_proto_tconv_patch(const void* src, const void* w, void* out, int nb, int h, int wd, int cin, int n, void* stream) {
+    if (!src || !w || !out || cin % 64 || n % 128 || cin < 128) return -1;
+    ProtoT k;
+    k.src = (const char*)src; k.w = (const char*)w; k.out = (char*)out;
+    k.nb = nb; k.h = h; k.w_ = wd; k.cin = cin; k.n = n;
+    k.tiles_y = (h + TY - 1) / TY; k.tiles_x = (wd + TX - 1) / TX; k.ntiles = n / 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_tconv_patch, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_tconv_patch, dim3(nb * k.tiles_y * k.tiles_x * 4 * k.ntiles), dim3(512), TLDS_BYTES, (hipStream_t)stream, k);
+    return (int)hipGetLastError();
+}
+
 // src [nb][hin][win][cin] bf16, w [n][16][cin] bf16, out [nb][hin-1][win-1][n] bf16; cin % 64 == 0, n % 128 == 0, win - 1 <= 32
 extern "C" int pfa_proto_conv_s1_patch(const void* src, const void* w, void* out, int nb, int hin, int win, int cin, int n,
                                        int staggered, int dbg, void* stream) {
