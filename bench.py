@@ -2,18 +2,27 @@
 """Headline benchmark: GAN img-pairs/s of the complete Pix2Pix G+D training step (train_gan.py:52-71:
 G fwd, 3x D fwd, both backwards, both Adam updates) at 256x256x3, batch 16 per GPU, bf16 operands.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One JSON line on rank 0.  `value` = N * batch * K / (max over ranks of the timed K steps), inputs resident in
-HBM (a pool of pre-packed synthetic batches, seed 1234 + rank).  Extra objects:
-  roofline      dominant kernel = the bf16 128x128-tile implicit-GEMM (k_gather_gemm<bf16,256,128,4,2,3>: 256x128 tile, 8 waves, 3-stage LDS ring): HIP-event
-                time of every launch of it over a pass of the same steps, against its algorithmic conv FLOPs
-                (2 * pixels * Cout * taps * Cin_real per launch; SURVEY 8d counts the same MACs)
-  cpu_baseline  the numpy oracle's gan_step (oracle/step.py, "port") on the host cores, bounded sample
+N > 1 without a torch.distributed environment: this process starts `python -m torch.distributed.run` with N ranks as a
+CHILD process (before anything here touches a GPU), relays rank 0's JSON line and exits with the child's code.
+
+One JSON line on rank 0.  `value` = N * batch * K / (max over ranks of the K timed steps), inputs resident in HBM (a pool
+of pre-packed synthetic batches, seed 1234 + rank).  The K-step measurement is repeated `--repeats` times (default 5,
+each bracketed by barrier + device synchronise) and the MEDIAN repeat is reported; all repeats are listed.
+Extra objects:
+  roofline      the MFMA kernel with the largest total time: HIP-event time of every launch of it (pfa_gather_timing,
+                recorded by the library on the launch stream) over a pass of the same steps on one stream, against its
+                algorithmic conv FLOPs (2 x MACs on real channels and taps: SURVEY 8d's count); `kernels` lists every
+                MFMA kernel family of the step, weight gradients included
+  cpu_baseline  the build's PyTorch-CPU restatement of the same step (pfa_gan.train_gan_one_epoch on CPU modules with
+                torch.optim.Adam, pinned to the reference by tests/test_host_cpu.py), B=1 and B=4, on the host cores
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,11 +31,12 @@ for _p in (ROOT, os.path.join(ROOT, "gan-aug-pfa_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch  # noqa: E402
-
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {256: 86.79e9, 512: 351.38e9}      # minimal schedule, conv MACs x2
+FLOP_PER_TILE = {256: 12.046e9, 512: 48.18e9}      # generator-only forward
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
 
 
 def parse():
@@ -34,12 +44,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of --steps steps; the median is reported")
     ap.add_argument("--batch", type=int, default=16, help="img-pairs per GPU (BASELINE config 2: 16)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--auto-graph", action="store_true", help="GanTrainer(use_graph='auto'): hipGraph replay for tiny batches")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step as three captured hipGraphs (default: eager launches on two HIP streams, which "
+                    help="replay the step as three captured hipGraphs (default: eager launches on three HIP streams, which "
                          "measured faster: the graph executor does not run the forked side-stream branch concurrently)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
@@ -47,31 +58,37 @@ def parse():
                     help="D(real) of a step waits for the whole previous step (A/B switch for inputs_resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE config 5: generator-only eval forward (generate_synthetic_data.py:55-68), tiles/s")
     return ap.parse_args()
 
 
-def kernel_roofline(trainer, xa, xb, steps, precision):
-    """Live measurement of the dominant kernel: libpfa_hip brackets every implicit-GEMM kernel launch with HIP events on
-    its launch stream (pfa_gather_timing; a split-K call's finish kernel stays outside) over `steps` eager one-stream
-    steps of the same workload; the instantiation with the largest total time is the dominant kernel and ALL its launches
-    count - the same population `rocprofv3 --kernel-trace --stats` averages for that kernel name
-    (profiles/r01_bench_b16_256_bf16_onestream_kernel_stats.csv is the same mode)."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a child process.  Nothing in
+    this process has touched a GPU (torch is not even imported yet); the child's rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    raise SystemExit(proc.returncode if proc.returncode else (0 if lines else 1))
+
+
+# ----------------------------------------------------------------------------------------------------- roofline
+def _timed_kernels(lib, _lib):
+    """{kernel name: [ms, flop, bytes, launches, sliced launches]} from the library's timing store."""
     import ctypes
-    from pfa_gan import _lib
-    lib = _lib.lib()
-    was_graph, was_side = trainer.use_graph, trainer.side
-    trainer.use_graph, trainer.side = False, None      # one stream: nothing else shares the GPU with the timed launches
-    lib.pfa_gather_timing(1)
-    try:
-        for _ in range(steps):
-            trainer.step_packed(xa, xb)
-        torch.cuda.synchronize()
-    finally:
-        lib.pfa_gather_timing(0)
-        trainer.use_graph, trainer.side = was_graph, was_side
     per = {}
     ms, name, flop, byts, sk = ctypes.c_float(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
     for i in range(lib.pfa_gather_timing_count()):
@@ -79,56 +96,161 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
                                              ctypes.byref(sk)), "pfa_gather_timing_get")
         r = per.setdefault(name.value.decode(), [0.0, 0.0, 0.0, 0, 0])
         r[0] += ms.value; r[1] += flop.value; r[2] += byts.value; r[3] += 1; r[4] += sk.value > 1
+    return per
+
+
+def _roofline_object(per, steps, peak, unit_flop_total, workload_key):
+    """The bench line's `roofline`: the kernel with the largest total time first, every MFMA kernel family in `kernels`."""
     kernel, (tms, tflop, tbytes, n, nsplit) = max(per.items(), key=lambda kv: kv[1][0])
-    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     achieved = tflop / (tms * 1e-3) / 1e12
-    traffic, traffic_src = None, None
-    tfile = os.path.join(ROOT, "profiles", "r01_traffic_gather_ring.json")
-    if precision == "bf16" and xa.shape[0] == 16 and xa.shape[1] == 256 and os.path.exists(tfile):
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/pmc_traffic.py);
-        # counters cannot be read from inside the process being measured
-        t = json.load(open(tfile))
-        if t.get("kernel") == kernel:
-            traffic, traffic_src = round(t["traffic_bytes_per_launch"]), "profiles/r01_traffic_gather_ring.json"
+    traffic = traffic_src = None
+    if os.path.exists(TRAFFIC_FILE):
+        # HBM bytes per launch from committed rocprofv3 PMC passes of this same workload: counters cannot be read from
+        # inside the process being measured.  The file names the commit and date it was taken at.
+        t = json.load(open(TRAFFIC_FILE))
+        ent = t.get("workloads", {}).get(workload_key, {}).get(kernel)
+        if ent:
+            traffic = round(ent["traffic_bytes_per_launch"])
+            traffic_src = f"profiles/{os.path.basename(TRAFFIC_FILE)} ({t.get('commit', '?')}, {t.get('date', '?')})"
     total_ms = sum(v[0] for v in per.values())
-    # every MFMA convolution kernel of the step, largest time first (the fields above `kernels` describe the first one)
     others = [dict(kernel=k, launches_per_step=v[3] // steps, avg_launch_us=round(1e3 * v[0] / v[3], 2),
                    achieved=round(v[1] / (v[0] * 1e-3) / 1e12, 2), frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4),
-                   share_of_implicit_gemm_time=round(v[0] / total_ms, 3))
+                   flop_share_of_step=round(v[1] / steps / unit_flop_total, 3) if unit_flop_total else None,
+                   share_of_mfma_kernel_time=round(v[0] / total_ms, 3))
               for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])]
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                 traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(tbytes / n),
-                kernel=kernel, launches_per_step=n // steps, split_k_launches_per_step=nsplit // steps,
+                kernel=kernel, launches_per_step=n // steps, sliced_launches_per_step=nsplit // steps,
                 avg_launch_us=round(1e3 * tms / n, 2), flop_per_launch=round(tflop / n),
-                flop_share_of_step=round(tflop / steps / (FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0] or 1), 3),
-                share_of_implicit_gemm_time=round(tms / total_ms, 3), kernels=others)
+                flop_share_of_step=round(tflop / steps / unit_flop_total, 3) if unit_flop_total else None,
+                share_of_mfma_kernel_time=round(tms / total_ms, 3),
+                all_mfma_kernels=dict(ms_per_step=round(total_ms / steps, 3),
+                                      achieved=round(sum(v[1] for v in per.values()) / (total_ms * 1e-3) / 1e12, 2)),
+                kernels=others)
 
 
-def cpu_baseline(size, steps):
-    """The CPU restatement of the same step (oracle/step.py) on this host's cores: 1 warm-up + `steps` timed."""
-    import numpy as np
-    from oracle import fill, nets, step as ostep
-    b = 1
-    gst = fill.fill_state(nets.g_state_shapes(), seed=0, bn_noise=False)
-    dst = fill.fill_state(nets.d_state_shapes(), seed=1, bn_noise=False)
-    go, do = ostep.new_adam_state(gst), ostep.new_adam_state(dst)
-    a = fill.uniform("cpu.a", (b, 3, size, size))
-    bb = fill.uniform("cpu.b", (b, 3, size, size))
-    ostep.gan_step(gst, dst, go, do, a, bb)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ostep.gan_step(gst, dst, go, do, a, bb)
-    dt = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    return dict(value=round(b * steps / dt, 4), unit="img-pairs/s", cores=cores, kind="port",
-                sample=f"oracle/step.py gan_step (numpy {np.__version__}, BLAS threads = cores), default nets, "
-                       f"{size}x{size}, batch {b}, {steps} steps after 1 warm-up, fp32")
+def kernel_roofline(trainer, xa, xb, steps, precision):
+    """Live measurement: libpfa_hip brackets every MFMA kernel launch (implicit GEMM, patch kernels, weight gradients) with
+    HIP events on its launch stream over `steps` eager one-stream steps of the same workload; ALL launches of a kernel
+    instantiation count - the population `rocprofv3 --kernel-trace --stats` averages for that kernel name
+    (profiles/r02_*_onestream_* is the same mode)."""
+    import torch
+    from pfa_gan import _lib
+    lib = _lib.lib()
+    was_graph, was_side, was_side2 = trainer.use_graph, trainer.side, trainer.side2
+    trainer.use_graph, trainer.side, trainer.side2 = False, None, None   # one stream: nothing shares the GPU with a timed launch
+    lib.pfa_gather_timing(1)
+    try:
+        for _ in range(steps):
+            trainer.step_packed(xa, xb)
+        torch.cuda.synchronize()
+    finally:
+        lib.pfa_gather_timing(0)
+        trainer.use_graph, trainer.side, trainer.side2 = was_graph, was_side, was_side2
+    per = _timed_kernels(lib, _lib)
+    peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
+    unit = FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0]
+    return _roofline_object(per, steps, peak, unit, f"train_b{xa.shape[0]}_{xa.shape[1]}_{precision}")
 
 
+# ----------------------------------------------------------------------------------------------------- CPU baseline
+def _cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, len(phys) or None, os.cpu_count(), usable
+
+
+def cpu_baseline(size, budget_s, infer=False):
+    """The reference's CPU path restated: pfa_gan modules on the CPU are plain PyTorch sub-modules (ATen / oneDNN, fp32)
+    and pfa_gan.train_gan_one_epoch then runs the reference's own sequence of calls (train_gan.py:52-71) with
+    torch.optim.Adam - what BASELINE.md section 5 specifies.  Batch 1 (the reference's BATCH_SIZE, train_gan.py:26) and
+    batch 4, 1 warm-up + 3 timed steps each, bounded by `budget_s`.  Thread count: every usable core, unless a quick
+    probe shows fewer threads are faster on this host (stated in `sample`)."""
+    import torch
+    import pfa_gan
+    model, phys, logical, usable = _cpu_info()
+    t_start = time.perf_counter()
+    torch.manual_seed(0)
+    gen = pfa_gan.UNetGenerator(3, 3)
+    disc = pfa_gan.NLayerDiscriminator(6)
+    og = torch.optim.Adam(gen.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(disc.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(1234)
+
+    def batches(b, n):
+        return [dict(image1=torch.rand((b, 3, size, size), generator=g) * 2 - 1,
+                     image2=torch.rand((b, 3, size, size), generator=g) * 2 - 1) for _ in range(n)]
+
+    def run(b, n):
+        if infer:
+            gen.eval()
+            xs = [bt["image1"] for bt in batches(b, n)]
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                for x in xs:
+                    gen(x)
+            return (time.perf_counter() - t0) / n
+        bs = batches(b, n)
+        t0 = time.perf_counter()
+        pfa_gan.train_gan_one_epoch(gen, disc, bs, og, od)
+        return (time.perf_counter() - t0) / n
+
+    # thread count: all usable cores (BASELINE.md section 5) unless fewer are measurably faster (small convolutions on
+    # very many threads spend their time in the thread pool)
+    cands = sorted({usable, min(usable, 64), min(usable, 32), min(usable, 16)}, reverse=True)
+    best_t, best_s = cands[0], None
+    for t in cands:
+        torch.set_num_threads(t)
+        run(4, 1)                                     # warm-up at this thread count
+        s = run(4, 1)
+        if best_s is None or s < best_s:
+            best_t, best_s = t, s
+        if time.perf_counter() - t_start > 0.4 * budget_s:
+            break
+    torch.set_num_threads(best_t)
+    res = {}
+    for b in (4, 1):
+        run(b, 1)
+        n = 3
+        s = run(b, n)
+        res[b] = (b / s, n)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    unit = "tiles/s" if infer else "img-pairs/s"
+    b_best = max(res, key=lambda b: res[b][0])
+    what = "generator eval forward (no_grad)" if infer else "train_gan_one_epoch on CPU modules + torch.optim.Adam"
+    return dict(value=round(res[b_best][0], 3), unit=unit, cores=best_t, kind="port",
+                by_batch={str(b): round(v[0], 3) for b, v in sorted(res.items())},
+                cpu_model=model, physical_cores=phys, logical_cores=logical, usable_cores=usable, threads=best_t,
+                torch=torch.__version__,
+                sample=f"pfa_gan {what}, default nets, {size}x{size}, fp32, batch "
+                       f"{' and '.join(str(b) for b in sorted(res))}: 1 warm-up + 3 timed steps each; value = batch {b_best}; "
+                       f"threads probed {cands[:cands.index(best_t) + 1] if best_t in cands else cands}, fastest {best_t}")
+
+
+# ----------------------------------------------------------------------------------------------------- inference (config 5)
 def infer_main(args):
     """BASELINE config 5: eval-mode generator forward over synthetic 256x256 tiles, hipGraph-captured, one GPU."""
+    import torch
     import pfa_gan
-    from pfa_gan import kernels as K
+    from pfa_gan import _lib, kernels as K
+    torch.cuda.set_device(0)
+    lib = _lib.lib()
     torch.manual_seed(0)
     gen = pfa_gan.UNetGenerator(3, 3).cuda().set_precision(args.precision).eval()
     eng = gen.engine()
@@ -136,45 +258,63 @@ def infer_main(args):
     ctx = eng.new_ctx()
     x = torch.rand((args.batch, 3, args.size, args.size), device="cuda") * 2 - 1
     xh = K.pack_nhwc(x, eng.dtype)
-    out_u8 = None
     for _ in range(3):
         eng.forward(xh, ctx, train=False)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        fake = eng.forward(xh, ctx, train=False)
+        eng.forward(xh, ctx, train=False)
     for _ in range(args.warmup):
         graph.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        graph.replay()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    dt = statistics.median(reps)
     tiles = args.batch * args.steps / dt
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
-    print(json.dumps({
+    flop_tile = FLOP_PER_TILE.get(args.size, 0)
+    out = {
         "metric": "generator-only eval forward, 256x256 tiles/s", "value": round(tiles, 1), "unit": "tiles/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+        "repeats_ms_per_step": [round(1e3 * r / args.steps, 3) for r in reps],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"UNetGenerator eval forward, {args.size}x{args.size}, batch {args.batch}, hipGraph replay"},
-        "step_mfma": {"algorithmic_tflops_per_gpu": round(tiles * 12.046e9 / 1e12, 2),
-                      "frac_of_peak": round(tiles * 12.046e9 / 1e12 / peak, 4)}}), flush=True)
+        "config": {"workload": f"UNetGenerator eval forward (generate_synthetic_data.py:55-68), {args.size}x{args.size}, "
+                               f"batch {args.batch}, hipGraph replay"},
+        "step_mfma": {"algorithmic_tflops_per_gpu": round(tiles * flop_tile / 1e12, 2),
+                      "frac_of_peak": round(tiles * flop_tile / 1e12 / peak, 4)}}
+    if not args.no_roofline:
+        n = max(2, min(args.steps, 5))
+        lib.pfa_gather_timing(1)
+        try:
+            for _ in range(n):
+                eng.forward(xh, ctx, train=False)
+            torch.cuda.synchronize()
+        finally:
+            lib.pfa_gather_timing(0)
+        out["roofline"] = _roofline_object(_timed_kernels(lib, _lib), n, peak, flop_tile * args.batch,
+                                           f"infer_b{args.batch}_{args.size}_{args.precision}")
+    if not args.no_cpu_baseline and args.size == 256:
+        out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds, infer=True)
+    print(json.dumps(out), flush=True)
 
 
 def main():
     args = parse()
     if args.mode == "infer":
-        torch.cuda.set_device(0)
         return infer_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                # never returns
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} "
-                             f"bench.py ...` (one process per GPU)")
         args.gpus = world
+    import torch
     # Rehearsal of the N-rank control flow on a one-GPU box (tests/test_gpu_networks.py): PFA_BENCH_BACKEND=gloo with
     # PFA_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and reduces through gloo.  The measured configuration is RCCL.
     backend = os.environ.get("PFA_BENCH_BACKEND", "nccl")
@@ -221,16 +361,20 @@ def main():
     launches0 = _lib.launch_count()
     for i in range(args.warmup):
         trainer.step_packed(*pool[i % len(pool)])
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        trainer.step_packed(*pool[i % len(pool)])
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tmax)
+    reps = []
+    for r in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):                  # EXACTLY --steps steps between the two barriers
+            trainer.step_packed(*pool[i % len(pool)])
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tmax)
+        reps.append(dt)
+    dt = statistics.median(reps)
     losses = trainer.losses.tolist()
     assert all(l == l and abs(l) < 1e6 for l in losses), f"non-finite loss {losses}"
     assert _lib.launch_count() > launches0
@@ -245,13 +389,16 @@ def main():
         out = {
             "metric": "GAN img-pairs/sec (G+D step, 256x256x3)" if args.size == 256 else f"GAN img-pairs/sec (G+D step, {args.size}x{args.size}x3)",
             "value": round(value, 2), "unit": "img-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "repeats_ms_per_step": [round(1e3 * r / args.steps, 3) for r in reps],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{args.size}x{args.size} RGB Pix2Pix G+D step (UNetGenerator num_downs=7 ngf=64 + "
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph x3 segments" if trainer.use_graph is True else
                                  ("eager, 3 HIP streams" if not args.no_overlap else "eager, 1 HIP stream"),
+                       "timing": f"median of {len(reps)} repeats of {args.steps} steps",
                        "last_losses": [round(l, 4) for l in losses]},
         }
         if flop_pair:
@@ -260,7 +407,7 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.size == 256:
-            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -18,17 +18,38 @@
 // 4 consecutive output channels of one pixel -> 8/16-byte NHWC stores.
 #include "pfa_common.h"
 
-int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits, ... (include/pfa_hip.h).  Relaxed atomics: the
+// library may be entered from several host threads / streams at once; a knob is a measurement switch, never a result.
+std::atomic<int> g_knob[8];
 static thread_local const char* g_last_gather_name = "";
 
 // Optional per-launch timing (pfa_gather_timing): HIP events recorded on the launch stream right before and right after the
-// implicit-GEMM kernel of a pfa_gather_gemm call (a split-K call's finish kernel is outside the bracket).
+// MFMA kernel of a pfa_gather_gemm / pfa_wgrad call (a split-K call's finish kernel and a weight gradient's reduce kernel
+// are outside the bracket).  The store is bounded: launches beyond TIMED_MAX while timing is on are not recorded.
 #include <mutex>
 #include <vector>
 struct TimedLaunch { hipEvent_t e0, e1; const char* name; double flop, bytes; int splitk; };
 static std::mutex g_timed_mu;
 static std::vector<TimedLaunch> g_timed;
-static bool g_timing = false;    // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits
+static std::atomic<bool> g_timing{false};
+constexpr size_t TIMED_MAX = 1 << 16;
+
+bool pfa_timing_begin(hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_timing.load(std::memory_order_relaxed)) return false;
+    {
+        std::lock_guard<std::mutex> lk(g_timed_mu);
+        if (g_timed.size() >= TIMED_MAX) return false;
+    }
+    if (hipEventCreate(e0) != hipSuccess) return false;
+    if (hipEventCreate(e1) != hipSuccess) { (void)hipEventDestroy(*e0); return false; }
+    (void)hipEventRecord(*e0, st);
+    return true;
+}
+void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk) {
+    (void)hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    g_timed.push_back(TimedLaunch{e0, e1, name, flop, bytes, splitk});
+}
 
 namespace {
 
@@ -64,6 +85,7 @@ struct GatherK {
     int bias_unaligned;      // bias pointer not 16-byte aligned: element-wise loads
     int coef_unaligned;      // likewise for the fuse_* arrays
     int stat_col0, stat_n;   // statistics cover output columns [stat_col0, stat_col0 + stat_n), row length stat_n
+    int small32;             // every operand and result tensor is below 2 GiB (32-bit byte offsets are safe)
 };
 
 template <typename T> struct Mma;
@@ -1178,10 +1200,11 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     const long long es = a->dtype == PFA_BF16 ? 2 : 4;
     const bool small32 = (long long)a->nb * a->hs * a->ws * (a->c1 > a->c2 ? a->c1 : a->c2) * es < (1ll << 31) &&
                          (long long)a->n * 16 * (a->c1 + a->c2) * es < (1ll << 31);
+    k.small32 = small32 && (long long)k.npix * (a->ld1 > a->ld2 ? a->ld1 : a->ld2) * es < (1ll << 31) ? 1 : 0;
     k.wide = (a->c1 % kstep_ch == 0 && a->c2 % kstep_ch == 0 && small32) ? 1 : 0;
     k.spt = k.wide ? k.ctot / kstep_ch : 1;
     k.sp1 = k.wide ? a->c1 / kstep_ch : 1;
-    k.dbg = g_knob[1];
+    k.dbg = pfa_knob(1);
     k.fuse_out = a->fuse_out; k.fuse_act1 = a->fuse_act1; k.fuse_act2 = a->fuse_act2;
     k.fuse_raw = (const char*)a->fuse_raw; k.fuse_g2 = (const char*)a->fuse_g2;
     k.fuse_scale = a->fuse_scale; k.fuse_shift = a->fuse_shift; k.fuse_mean = a->fuse_mean; k.fuse_invstd = a->fuse_invstd;
@@ -1233,24 +1256,24 @@ inline TileCfg choose_cfg(const GatherK& k) {
     if (k.n <= 64) {
         // 256x64 with the 3-stage ring (8 waves, 120 KiB) for the wide launches with enough tiles; else 128x64
         const long long tiles = (long long)((k.M + 255) / 256) * (k.mode == PFA_TCONV_S2 ? 4 : 1) * k.splitk;
-        const bool ring_ok = k.wide && k.kper >= 3 && tiles >= (g_knob[6] > 0 ? g_knob[6] : RING_MIN_TILES);
+        const bool ring_ok = k.wide && k.kper >= 3 && tiles >= (pfa_knob(6) > 0 ? pfa_knob(6) : RING_MIN_TILES);
         // (measured slower than 128x64 reads-first: d2 forward 75 vs 61 us, -1 % in the step: knob 7 = 2 enables it)
-        if (g_knob[0] == 5 || (g_knob[0] == 0 && ring_ok && g_knob[7] == 2)) return cfgs[4];
+        if (pfa_knob(0) == 5 || (pfa_knob(0) == 0 && ring_ok && pfa_knob(7) == 2)) return cfgs[4];
         return cfgs[1];
     }
     // Default: 128x128 at two workgroups per CU.  The 256x128 tile (85 FLOP per staged byte) is 3-5 % faster per layer in
     // isolation (tools/layer_bench.py) but not inside the three-stream step, where its 96 KiB of LDS per workgroup leaves
     // less room for the co-running weight-gradient kernels (same-box A/B: 3168 vs 3187 pairs/s); it stays selectable.
-    if (g_knob[0] == 4 || g_knob[0] == 8) return cfgs[3];     // 8: with the 3-stage ring where it applies
-    if (g_knob[0] == 0) {
+    if (pfa_knob(0) == 4 || pfa_knob(0) == 8) return cfgs[3];     // 8: with the 3-stage ring where it applies
+    if (pfa_knob(0) == 0) {
         // Default for n >= 128: the 256x128 tile with the 3-stage ring (one 8-wave workgroup owns the CU, the DMA queue
         // is never drained) wherever the launch still has enough 256-row tiles; +4.6 % pairs/s over 128x128 everywhere.
         const long long tiles256 = (long long)((k.M + 255) / 256) * ((k.n + 127) / 128) * (k.mode == PFA_TCONV_S2 ? 4 : 1) *
                                    k.splitk;
-        const int thr = g_knob[6] > 0 ? g_knob[6] : RING_MIN_TILES;
+        const int thr = pfa_knob(6) > 0 ? pfa_knob(6) : RING_MIN_TILES;
         if (k.wide && k.kper >= 3 && tiles256 >= thr) return cfgs[3];
     }
-    if (g_knob[0] == 6) return cfgs[1];              // experiment: 128x64 everywhere
+    if (pfa_knob(0) == 6) return cfgs[1];              // experiment: 128x64 everywhere
     // (128x64 for unsplit launches with one 128x128 workgroup per CU: -14 % on e3/c3 forward in isolation, nothing in
     //  the step - not enabled.)
     return cfgs[0];
@@ -1270,14 +1293,15 @@ inline int fill_params_geometry(const pfa_gather_args* a, GatherK& k, int& class
 // epilogue rides on the finish pass, i.e. needs a K-sliced launch.  pfa_set_knob(3, 1) turns the route off, 2 takes it
 // whenever the geometry fits (tests).
 inline bool patch_route(const pfa_gather_args* a, const GatherK& k, int* tiles) {
-    if (g_knob[3] == 1) return false;
+    if (pfa_knob(3) == 1) return false;
+    if (!k.small32) return false;          // the patch kernel builds 32-bit byte offsets: tensors of 2 GiB and more stay on the implicit GEMM
     const bool fwd = a->mode == PFA_CONV_S1, grad = a->mode == PFA_CONV_S1_DGRAD;
     if (!((fwd || grad) && a->dtype == PFA_BF16 && a->c2 == 0 && a->bias == nullptr && a->act == PFA_ACT_NONE &&
           a->n1 >= a->n && a->ld1 == a->n && a->ld2 == 0 && (a->fuse_out == 0 || (a->fuse_out != 3 && k.splitk > 1))))
         return false;
     int t = 0;
     if (!pfa_conv_s1_patch_ok(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &t)) return false;
-    if (g_knob[3] != 2 && (long long)t * (a->n / 128) * k.splitk < 128) return false;
+    if (pfa_knob(3) != 2 && (long long)t * (a->n / 128) * k.splitk < 128) return false;
     if (tiles) *tiles = t;
     return true;
 }
@@ -1312,7 +1336,7 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
 //   order 2 (channel-major, needs >= 8 n-tiles): all pixels, its share of the weights   ->  8*A + W
 // Measured with rocprofv3 FETCH_SIZE inside a step (tools/step_traffic.py): d2 forward 472 -> see DESIGN section 6.
 static int choose_order(const GatherK& k) {
-    if (g_knob[5] >= 1 && g_knob[5] <= 3) return g_knob[5] - 1;
+    if (pfa_knob(5) >= 1 && pfa_knob(5) <= 3) return pfa_knob(5) - 1;
     const double A = (double)k.nb * k.hs * k.ws * k.ctot;
     const double W = (double)k.n * 16 * k.ctot;
     const double P = (double)k.splitk * k.classes;
@@ -1351,8 +1375,8 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
     // default K-loop per tile shape (tools/layer_bench.py): spreading the DMA pays on the 128x128 tile; the 128x64 tile
     // (16 MFMAs per wave and K-step, three to four workgroups per CU) is 30-40 % faster with the plain reads-first loop
     static const int default_early[] = {2, 0, 1, 1, 1};
-    int early = g_knob[2] >= 1 && g_knob[2] <= 3 ? g_knob[2] - 1 : default_early[cfg];
-    if ((g_knob[0] == 8 || g_knob[0] == 0) && cfg == 3 && g_knob[2] == 0) early = 2;    // 256x128: the 3-stage ring
+    int early = pfa_knob(2) >= 1 && pfa_knob(2) <= 3 ? pfa_knob(2) - 1 : default_early[cfg];
+    if ((pfa_knob(0) == 8 || pfa_knob(0) == 0) && cfg == 3 && pfa_knob(2) == 0) early = 2;    // 256x128: the 3-stage ring
     // (narrow-staging launches on the 128x128 tile keep the spread loop: reads-first measured 40 % slower there)
     switch (cfg * 3 + early) {
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);
@@ -1360,7 +1384,7 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 2: return launch_gather<T, 128, 128, 2, 2, 2>(k, classes, st);
         case 3:
             // knob 7 = 5: three-stage ring on the 128x64 tile (72 KiB: still two workgroups per CU)
-            if (g_knob[7] == 5 && k.wide && k.kper >= 3) return launch_gather<T, 128, 64, 2, 2, 3>(k, classes, st);
+            if (pfa_knob(7) == 5 && k.wide && k.kper >= 3) return launch_gather<T, 128, 64, 2, 2, 3>(k, classes, st);
             return launch_gather<T, 128, 64, 2, 2, 0>(k, classes, st);
         case 4: return launch_gather<T, 128, 64, 2, 2, 1>(k, classes, st);
         case 5: return launch_gather<T, 128, 64, 2, 2, 2>(k, classes, st);
@@ -1371,9 +1395,9 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
         case 11:
             // knob 2 = 3 on the 256x128 tile: the 3-stage ring (wide launches with at least three K-steps per slice)
             if (k.wide && k.kper >= 3)
-                return g_knob[7] == 4   ? launch_gather<T, 256, 128, 4, 2, 4>(k, classes, st)      // half-step pipelined ring
-                       : g_knob[7] == 6 ? launch_gather<T, 256, 128, 4, 2, 5>(k, classes, st)      // staggered ring
-                       : g_knob[7] == 7 ? launch_gather<T, 256, 128, 4, 2, 6>(k, classes, st)      // staggered, half-step phases
+                return pfa_knob(7) == 4   ? launch_gather<T, 256, 128, 4, 2, 4>(k, classes, st)      // half-step pipelined ring
+                       : pfa_knob(7) == 6 ? launch_gather<T, 256, 128, 4, 2, 5>(k, classes, st)      // staggered ring
+                       : pfa_knob(7) == 7 ? launch_gather<T, 256, 128, 4, 2, 6>(k, classes, st)      // staggered, half-step phases
                                         : launch_gather<T, 256, 128, 4, 2, 3>(k, classes, st);
             return launch_gather<T, 256, 128, 4, 2, 1>(k, classes, st);
         default:
@@ -1390,7 +1414,7 @@ extern "C" int pfa_gather_timing(int enable) {
         for (auto& t : g_timed) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); }
         g_timed.clear();
     }
-    g_timing = enable != 0;
+    g_timing.store(enable != 0);
     return 0;
 }
 
@@ -1411,7 +1435,7 @@ extern "C" int pfa_gather_timing_get(int i, float* ms, const char** name, double
 
 extern "C" int pfa_set_knob(int id, int value) {
     PFA_REQUIRE(id >= 0 && id < 8, "pfa_set_knob: id out of range");
-    g_knob[id] = value;
+    g_knob[id].store(value, std::memory_order_relaxed);
     return 0;
 }
 
@@ -1481,13 +1505,8 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     int rc;
     GatherK kk = k;
     if (k.splitk > 1) { kk.bias = nullptr; kk.psum = kk.psq = nullptr; }   // applied by the finish pass
-    TimedLaunch tl{};
-    const bool timing = g_timing;
-    if (timing) {
-        (void)hipEventCreate(&tl.e0);
-        (void)hipEventCreate(&tl.e1);
-        (void)hipEventRecord(tl.e0, st);
-    }
+    hipEvent_t te0, te1;
+    const bool timing = pfa_timing_begin(st, &te0, &te1);
     if (patch) {
         rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
                                a->nb, a->hs, a->ws, a->c1, a->n, st);
@@ -1497,16 +1516,17 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
                                   : dispatch_gather<float>(kk, classes, cfg.id, st);
     }
     if (timing) {
-        (void)hipEventRecord(tl.e1, st);
         const double es = a->dtype == PFA_BF16 ? 2.0 : 4.0, taps = a->mode == PFA_TCONV_S2 ? 4.0 : 16.0;
-        tl.name = g_last_gather_name;
-        tl.splitk = k.splitk;
-        tl.flop = 2.0 * (double)k.M * classes * k.n * taps * k.ctot;
+        // algorithmic FLOPs = 2 x the MACs of the convolution this launch is (or is the gradient of), on REAL channels
+        // (a->c_real; SURVEY 8d counts the same): a stride-1 input gradient has the forward's MACs, i.e. its rows are
+        // the source grid (hs x ws), not the padded position grid
+        const double creal = a->c_real > 0 ? a->c_real : k.ctot;
+        const double rows = a->mode == PFA_CONV_S1_DGRAD ? (double)a->nb * a->hs * a->ws : (double)k.M * classes;
+        const double flop = 2.0 * rows * k.n * taps * creal;
         // unique operand + result bytes: both sources, the weight rows used, the output rows written
-        tl.bytes = es * ((double)a->nb * a->hs * a->ws * k.ctot + (double)k.n * 16.0 * k.ctot +
-                         (double)k.npix * (a->ld1 + a->ld2));
-        std::lock_guard<std::mutex> lk(g_timed_mu);
-        g_timed.push_back(tl);
+        const double bytes = es * ((double)a->nb * a->hs * a->ws * k.ctot + (double)k.n * 16.0 * k.ctot +
+                                   (double)k.npix * (a->ld1 + a->ld2));
+        pfa_timing_end(st, te0, te1, g_last_gather_name, flop, bytes, k.splitk);
     }
     if (rc) return rc;
     if (k.splitk > 1) {

@@ -17,7 +17,6 @@
 // The reduction is sliced over blockIdx.z; slices combine with float32 atomics (dw is pre-zeroed).
 #include "pfa_common.h"
 
-extern int g_knob[8];
 constexpr int WGRAD_DEFAULT_EARLY = 0;
 
 namespace {
@@ -467,8 +466,8 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     k.magic_wq = (unsigned)(0x100000000ull / (unsigned)a->wq);
     if (hw == 1) k.magic_hw = 0xffffffffu;
     if (a->wq == 1) k.magic_wq = 0xffffffffu;
-    k.dbg = g_knob[1];
-    k.early = g_knob[4] == 1 ? 0 : g_knob[4] == 2 ? 1 : WGRAD_DEFAULT_EARLY;
+    k.dbg = pfa_knob(1);
+    k.early = pfa_knob(4) == 1 ? 0 : pfa_knob(4) == 2 ? 1 : WGRAD_DEFAULT_EARLY;
     k.jtot = 16 * k.gp;
     small_i = k.dp <= 16;
     msplit = a->msplit < 1 ? 1 : a->msplit;
@@ -476,8 +475,8 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     // workgroups, each reducing two 64-pixel half-steps per step - half the partial tiles to write and reduce
     // (e3/c3 43 -> 39 us, e4 49 -> 40 us; +2.2 % pairs/s, +2.0 % when pairing from four slices on only).  knob 4 = 5
     // turns them off, 6 pairs from four slices on; the explicit loop variants (knob 4 = 1..3) keep the 4-wave tile.
-    const int pair_min = g_knob[4] == 6 ? 4 : 2;
-    k.kgroups = ((g_knob[4] == 0 || g_knob[4] == 4 || g_knob[4] == 6) && a->dtype == PFA_BF16 && !small_i && msplit >= pair_min) ? 2 : 1;
+    const int pair_min = pfa_knob(4) == 6 ? 4 : 2;
+    k.kgroups = ((pfa_knob(4) == 0 || pfa_knob(4) == 4 || pfa_knob(4) == 6) && a->dtype == PFA_BF16 && !small_i && msplit >= pair_min) ? 2 : 1;
     if (k.kgroups == 2) msplit = (msplit + 1) / 2;
     const int km = (a->dtype == PFA_BF16 ? 64 : 32) * k.kgroups;
     k.step_img = km / hw;
@@ -494,7 +493,7 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
 // 256-row tile with the 3-stage ring: bf16 layers with at least 256 direct channels and a K loop long enough for a ring
 static bool wgrad_ring(const pfa_wgrad_args* a, const WgradK& k) {
     // (measured 3 % slower than the 128-row two-stage tile on the step's layers, tools/wgrad_bench.py: off unless knob 4 = 3)
-    return a->dtype == PFA_BF16 && k.dp >= 256 && k.mper >= 3 * 64 && g_knob[4] == 3;
+    return a->dtype == PFA_BF16 && k.dp >= 256 && k.mper >= 3 * 64 && pfa_knob(4) == 3;
 }
 
 extern "C" size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a) {
@@ -509,10 +508,25 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     if (int rc = wgrad_setup(a, k, msplit, small_i)) return rc;
     hipStream_t st = (hipStream_t)s;
 
+    hipEvent_t te0, te1;
+    const bool timing = pfa_timing_begin(st, &te0, &te1);
+    int rc;
+    const char* name;
     if (a->dtype == PFA_BF16) {
-        if (!small_i && wgrad_ring(a, k)) return launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st);
-        if (k.kgroups == 2) return launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st);
-        return small_i ? launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st) : launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st);
+        if (!small_i && wgrad_ring(a, k)) { rc = launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st); name = "k_wgrad<bf16,256,ring>"; }
+        else if (k.kgroups == 2) { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st); name = "k_wgrad<bf16,128,kg2>"; }
+        else if (small_i) { rc = launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st); name = "k_wgrad<bf16,16>"; }
+        else { rc = launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st); name = "k_wgrad<bf16,128>"; }
+    } else {
+        rc = small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);
+        name = small_i ? "k_wgrad<f32,16>" : "k_wgrad<f32,128>";
     }
-    return small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);
+    if (timing) {
+        // algorithmic FLOPs: the MACs of the layer's forward on real channels; bytes: both operands once + the gradient
+        const double es = a->dtype == PFA_BF16 ? 2.0 : 4.0;
+        const double flop = 2.0 * (double)k.M * 16.0 * (double)(k.d1r + k.d2r) * (double)k.gr;
+        const double bytes = es * ((double)k.M * k.dp + (double)a->nb * a->hg * a->wg * k.gp) + 4.0 * (double)(k.d1r + k.d2r) * 16.0 * k.gr;
+        pfa_timing_end(st, te0, te1, name, flop, bytes, msplit);
+    }
+    return rc;
 }

@@ -23,7 +23,7 @@ class GatherArgs(Structure):
         ("act", c_int32), ("slope", c_float), ("splitk", c_int32), ("ntiles_stat", c_int32),
         ("src1", c_void_p), ("src2", c_void_p), ("w", c_void_p), ("bias", c_void_p),
         ("out1", c_void_p), ("out2", c_void_p), ("psum", c_void_p), ("psq", c_void_p), ("slab", c_void_p),
-        ("fuse_out", c_int32), ("fuse_act1", c_int32), ("fuse_act2", c_int32), ("reserved", c_int32),
+        ("fuse_out", c_int32), ("fuse_act1", c_int32), ("fuse_act2", c_int32), ("c_real", c_int32),
         ("fuse_raw", c_void_p), ("fuse_g2", c_void_p), ("fuse_scale", c_void_p), ("fuse_shift", c_void_p),
         ("fuse_mean", c_void_p), ("fuse_invstd", c_void_p),
     ]

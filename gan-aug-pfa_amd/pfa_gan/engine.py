@@ -402,13 +402,13 @@ class GeneratorEngine(_Engine):
                 # has no norm at all (identity map), so it takes this route in training too: its backward reads the
                 # activation sign from aL, never the raw output.
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aL, aR], (B, h, w), self.ws, act=K.ACT_LRELU,
-                              affine=self._eval_affine(L, ctx, f"e{k}") + (K.ACT_RELU,))
+                              affine=self._eval_affine(L, ctx, f"e{k}") + (K.ACT_RELU,), c_real=sum(L.in_real))
                 ctx.v["aL"][k], ctx.v["aR"][k] = aL, aR
                 a = aL
                 continue
             raw = ctx.buf(f"e{k}.raw", shape, dt)
             if L.bn is None:        # outermost: no norm
-                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws)
+                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws, c_real=sum(L.in_real))
                 K.bn_act(raw, None, None, aL, aR)
             else:
                 st = K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
@@ -601,7 +601,7 @@ class DiscriminatorEngine(_Engine):
             if L.bn is None:
                 out = ctx.buf(f"c{i}.a", shape, dt)
                 K.gather_gemm(mode, a, L.w_fwd, L.cout, [out], (B, ho, wo), self.ws, bias=L.b,
-                              act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE)
+                              act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE, c_real=sum(L.in_real))
             else:
                 raw = ctx.buf(f"c{i}.raw", shape, dt)
                 st = K.gather_gemm(mode, a, L.w_fwd, L.cout, [raw], (B, ho, wo), self.ws, bias=L.b, stats=train)

@@ -121,7 +121,7 @@ def fuse_ok(mode, srcs, n, grid, single_ld=None):
 
 
 def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None,
-                affine=None):
+                affine=None, c_real=0):
     """out = act(bias + implicit_gemm(srcs, w)).  srcs/outs: lists of 1 or 2 NHWC tensors.
 
     grid = (nb, hq, wq) position grid.  Returns (psum, psq, ntiles) views when stats=True.
@@ -130,6 +130,7 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     mean/invstd the call returns (part, None, ntiles) for bn_bwd_finalize.
     affine: (scale, shift, act2) - eval-mode BatchNorm in the epilogue: outs[0] = act(scale*acc + shift) and, with two
     outs, outs[1] = act2(scale*acc + shift) over the same columns (needs splitk == 1: check auto_splitk first).
+    c_real: real (unpadded) contraction channels, for the FLOP accounting of pfa_gather_timing only (0 = as padded).
     """
     _require_cuda(*srcs, w, *outs)
     dtype = srcs[0].dtype
@@ -145,6 +146,7 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     a.ld2 = outs[1].shape[3] if len(outs) > 1 else 0
     a.n1 = outs[0].shape[3]
     a.act, a.slope = act, SLOPE
+    a.c_real = c_real
     M = grid[0] * grid[1] * grid[2]
     a.splitk = choose_splitk(mode, M, n, a.c1 + a.c2, dtype) if splitk is None else splitk
     a.src1, a.src2 = ptr(srcs[0]), ptr(srcs[1]) if len(srcs) > 1 else None

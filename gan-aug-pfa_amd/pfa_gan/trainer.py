@@ -38,8 +38,16 @@ class FusedAdam(torch.optim.Optimizer):
             raise PfaError("FusedAdam supports a single parameter group")
         self._flat = None
         self.m = self.v = None
-        self.steps = 0
-        self.step_dev = None
+        self.steps = 0          # host step count: THE step count (eager launches pass it by value)
+        self.step_dev = None    # device copy read by captured launches; _dev_steps = the value it holds
+        self._dev_steps = 0
+
+    def sync_step_dev(self):
+        """Make the device-side counter equal to the host count before a launch that reads it (hipGraph replay).  Eager
+        steps (a ragged batch between two replays, step_begin / step_range) advance only the host count."""
+        if self._dev_steps != self.steps:
+            self.step_dev.fill_(self.steps)
+            self._dev_steps = self.steps
 
     def flat(self):
         if self._flat is None or not self._flat.bound():
@@ -56,6 +64,7 @@ class FusedAdam(torch.optim.Optimizer):
                 self.m = torch.zeros_like(flat.data)
                 self.v = torch.zeros_like(flat.data)
                 self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
+                self._dev_steps = 0
             self._flat = flat
         return self._flat
 
@@ -75,10 +84,13 @@ class FusedAdam(torch.optim.Optimizer):
         flat = self.flat()
         g = self.param_groups[0]
         g2 = self._grad2 if use_grad2 else None
+        if graph_safe:
+            self.sync_step_dev()
         self.steps += 1
         flat.epoch += 1          # the arena is written behind torch's version counters
         if graph_safe:      # step count read from device memory so that a captured launch stays valid on replay
             K.adam_tick(self.step_dev)
+            self._dev_steps += 1
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0,
                    step_dev=self.step_dev, grad_scale=grad_scale, g2=g2)
         else:
@@ -112,6 +124,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.step_dev.fill_(self.steps)
+        self._dev_steps = self.steps
         self.param_groups[0].update(sd["param_groups"][0])
 
 
@@ -329,7 +342,14 @@ class GanTrainer:
         return self.losses
 
     def step(self, real_a, real_b):
-        return self.step_packed(self.pack(real_a), self.pack(real_b))
+        xa, xb = self.pack(real_a), self.pack(real_b)
+        ready = None
+        if self.side is not None:
+            # the pack kernels run on the current stream; D(real) starts on the side stream, which with
+            # inputs_resident waits for the previous step's events only - so hand it the packs' completion
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+        return self.step_packed(xa, xb, ready=ready)
 
     def _step_graph(self, xa, xb):
         """The same three segments captured once as hipGraphs (static shapes and addresses); the gradient
@@ -349,6 +369,8 @@ class GanTrainer:
             sa.copy_(xa)
             sb.copy_(xb)
             # warm-up outside capture: allocates every context buffer and workspace
+            for o in (self.opt_g, self.opt_d):    # outside the capture: a captured fill would reset the counter on every replay
+                o.sync_step_dev()
             state = self._snapshot()
             for _ in range(2):
                 self._d_phase(sa, sb, True)
@@ -368,13 +390,20 @@ class GanTrainer:
         sa, sb = self._static
         sa.copy_(xa)
         sb.copy_(xb)
+        for o in (self.opt_g, self.opt_d):        # an eager step since the last replay moved only the host count
+            o.sync_step_dev()
         self._graphs[0].replay()
         self._allreduce(self.opt_d)
         self._graphs[1].replay()
         self._allreduce(self.opt_g)
         self._graphs[2].replay()
-        self.opt_g.steps += 1
-        self.opt_d.steps += 1
+        for o in (self.opt_g, self.opt_d):        # each replay ticks the device counter once
+            o.steps += 1
+            o._dev_steps += 1
+        # the replay wrote parameters and BatchNorm buffers behind torch's version counters: cached eval-mode
+        # coefficients (save_samples between epochs) are stale from here
+        self.G.bn_epoch += 1
+        self.Dn.bn_epoch += 1
         self.nsteps += 1
         return self.losses
 
@@ -382,15 +411,16 @@ class GanTrainer:
         bufs = [b for m in (self.gen, self.disc) for b in m.buffers()]
         return dict(g=self.opt_g.flat().data.clone(), d=self.opt_d.flat().data.clone(),
                     gm=self.opt_g.m.clone(), gv=self.opt_g.v.clone(), dm=self.opt_d.m.clone(), dv=self.opt_d.v.clone(),
-                    gs=(self.opt_g.steps, self.opt_g.step_dev.clone()), ds=(self.opt_d.steps, self.opt_d.step_dev.clone()),
+                    gs=(self.opt_g.steps, self.opt_g.step_dev.clone(), self.opt_g._dev_steps),
+                    ds=(self.opt_d.steps, self.opt_d.step_dev.clone(), self.opt_d._dev_steps),
                     bufs=[b.clone() for b in bufs], sums=self.loss_sums.clone())
 
     def _restore(self, st):
         self.opt_g.flat().data.copy_(st["g"]); self.opt_d.flat().data.copy_(st["d"])
         self.opt_g.m.copy_(st["gm"]); self.opt_g.v.copy_(st["gv"])
         self.opt_d.m.copy_(st["dm"]); self.opt_d.v.copy_(st["dv"])
-        self.opt_g.steps = st["gs"][0]; self.opt_g.step_dev.copy_(st["gs"][1])
-        self.opt_d.steps = st["ds"][0]; self.opt_d.step_dev.copy_(st["ds"][1])
+        self.opt_g.steps = st["gs"][0]; self.opt_g.step_dev.copy_(st["gs"][1]); self.opt_g._dev_steps = st["gs"][2]
+        self.opt_d.steps = st["ds"][0]; self.opt_d.step_dev.copy_(st["ds"][1]); self.opt_d._dev_steps = st["ds"][2]
         bufs = [b for m in (self.gen, self.disc) for b in m.buffers()]
         for b, s in zip(bufs, st["bufs"]):
             b.copy_(s)
@@ -469,6 +499,17 @@ def load_training_state(ckpt_dir, gen, disc, opt_g, opt_d, device):
     return e
 
 
+def _all_have_batch(have, process_group, device):
+    """Data parallel: a batch that collates to None (collate_fn_skip_none, dataset.py:13-18) on ONE rank must be skipped
+    on EVERY rank - the others would otherwise enter the gradient all-reduces alone and hang.  Blocking form (one tiny
+    MIN all-reduce + host read per iteration); the fused path overlaps the same exchange with the previous step."""
+    if process_group is None:
+        return have
+    flag = torch.tensor([1 if have else 0], dtype=torch.int32, device=device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=process_group)
+    return bool(flag.item())
+
+
 def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=LAMBDA_L1, process_group=None):
     """Same contract as the reference's train_gan_one_epoch (train_gan.py:46-75): iterates `loader` (dict
     batches with "image1"/"image2"), returns (mean loss_d, mean loss_g).
@@ -491,37 +532,63 @@ def train_gan_one_epoch(gen, disc, loader, opt_g, opt_d, device=None, lambda_l1=
         main = torch.cuda.current_stream()
 
         def stage(batch):
+            """-> (xa, xb, ready event, agree) - agree() is None on one GPU; under a process group it tells, when the step
+            is due, whether EVERY rank has this batch (see _all_have_batch): the MIN all-reduce of the flag is issued
+            here, on the input stream, one iteration ahead, so that its result is on the host long before it is read."""
             in_stream.wait_stream(main)         # (allocator safety: buffers released on main are reusable here)
+            xa = xb = ev = agree = None
             with torch.cuda.stream(in_stream):
-                a = batch["image1"].to(device, non_blocking=True)
-                b = batch["image2"].to(device, non_blocking=True)
-                xa, xb = tr.pack(a), tr.pack(b)
-                ev = torch.cuda.Event()
-                ev.record(in_stream)
+                if batch is not None:
+                    a = batch["image1"].to(device, non_blocking=True)
+                    b = batch["image2"].to(device, non_blocking=True)
+                    xa, xb = tr.pack(a), tr.pack(b)
+                    ev = torch.cuda.Event()
+                    ev.record(in_stream)
+                if process_group is not None:
+                    flag = torch.tensor([0 if batch is None else 1], dtype=torch.int32).to(device, non_blocking=True)
+                    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=process_group,
+                                                 async_op=True).wait()      # the input stream waits, not the host
+                    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    host.copy_(flag, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(in_stream)
+
+                    def agree(done=done, host=host, flag=flag):
+                        done.synchronize()
+                        return bool(host.item())
             for t in (xa, xb):                  # used on the trainer's streams: keep the blocks out of reuse until then
+                if t is None:
+                    continue
                 t.record_stream(main)
                 for st in (tr.side, tr.side2):
                     if st is not None:
                         t.record_stream(st)
-            return xa, xb, ev
+            return xa, xb, ev, agree
+
+        def run(staged):
+            xa, xb, ev, agree = staged
+            if agree is not None and not agree():
+                return                          # some rank has no batch here: every rank skips the step
+            if xa is not None:
+                tr.step_packed(xa, xb, ev)
 
         staged = None
         for batch in loader:
-            if batch is None:
+            if batch is None and process_group is None:
                 continue
             nxt = stage(batch)
             if staged is not None:
-                tr.step_packed(*staged)
+                run(staged)
             staged = nxt
         if staged is not None:
-            tr.step_packed(*staged)
+            run(staged)
         return tr.epoch_losses()
     bce = torch.nn.BCEWithLogitsLoss()
     l1 = torch.nn.L1Loss()
     sum_d = sum_g = 0.0
     n = 0
     for batch in loader:
-        if batch is None:
+        if not _all_have_batch(batch is not None, process_group, device):
             continue
         real_a, real_b = batch["image1"].to(device), batch["image2"].to(device)
         opt_d.zero_grad()

@@ -68,11 +68,13 @@ int pfa_set_knob(int id, int value);
 /* Kernel instantiation the calling thread's most recent pfa_gather_gemm launched, e.g. "k_gather_gemm<bf16,256,128,4,2,3>"
  * (tile rows, tile columns, wave grid, K-loop variant): lets a profiler script attribute a launch to a kernel name. */
 const char* pfa_last_gather_kernel(void);
-/* Per-launch timing for measurements (bench.py's roofline object): while enabled, every pfa_gather_gemm call records one
- * HIP event on its launch stream right before and one right after its implicit-GEMM kernel (the finish kernel of a
- * split-K call stays outside).  pfa_gather_timing(1) clears the store and starts, (0) stops; after synchronising the
- * stream, pfa_gather_timing_get(i, ...) returns launch i's kernel time in ms, its instantiation name, its algorithmic
- * FLOPs (2 x rows x n x taps x padded channels), its unique operand + result bytes and its K-slice count. */
+/* Per-launch timing for measurements (bench.py's roofline object): while enabled, every pfa_gather_gemm and pfa_wgrad
+ * call records one HIP event on its launch stream right before and one right after its MFMA kernel (the finish kernel of a
+ * split-K call and the reduce kernel of a weight gradient stay outside).  pfa_gather_timing(1) clears the store and
+ * starts, (0) stops; after synchronising the stream, pfa_gather_timing_get(i, ...) returns launch i's kernel time in ms,
+ * its instantiation name, its algorithmic FLOPs (2 x the MACs of the convolution on REAL channels and real taps: the
+ * count of SURVEY 8d), its unique operand + result bytes and its K-slice (reduction-slice) count.  At most 65536
+ * launches are kept per enable. */
 int pfa_gather_timing(int enable);
 int pfa_gather_timing_count(void);
 int pfa_gather_timing_get(int i, float* ms, const char** name, double* flop, double* bytes, int* splitk);
@@ -118,7 +120,8 @@ typedef struct pfa_gather_args {
      * sums of dy and dy*xhat over the fused output's columns (row length = its ld) for pfa_bn_bwd_finalize. */
     int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2, 3 = affine epilogue (below)      */
     int32_t fuse_act1, fuse_act2;
-    int32_t reserved;
+    int32_t c_real;              /* real (unpadded) contraction channels of src1|src2 for the FLOP accounting of      */
+                                 /* pfa_gather_timing only; 0 = c1 + c2.  Never changes a result.                     */
     const void* fuse_raw;
     const void* fuse_g2;         /* optional second gradient w.r.t. the same tensor              */
     const float* fuse_scale;

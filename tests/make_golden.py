@@ -321,6 +321,55 @@ def gen_full(models):
     print("full.npz", len(s), "arrays")
 
 
+def gen_full512(models):
+    """BASELINE config 4's tile size: default networks at 512x512 (every map twice as wide, D logits 62x62): digests."""
+    s = {}
+    torch.set_num_threads(8)
+    G = models.UNetGenerator(3, 3)
+    gst = fill.fill_state(nets.g_state_shapes(), seed=3)
+    load_state(G, gst)
+    D = models.NLayerDiscriminator(6)
+    load_state(D, fill.fill_state(nets.d_state_shapes(), seed=4))
+    x = fill.uniform("full512.x", (1, 3, 512, 512))
+    G.train()
+    with torch.no_grad():
+        y = G(t(x)).numpy()
+    put_digest(s, "full512.g.y", y)
+    s["full512.g.y_chan_mean"] = y.astype(np.float64).mean(axis=(0, 2, 3))
+    xd = fill.uniform("full512.xd", (1, 6, 512, 512))
+    D.train()
+    with torch.no_grad():
+        yd = D(t(xd)).numpy()
+    assert yd.shape == (1, 1, 62, 62)
+    s["full512.d.y"] = yd
+    np.savez_compressed(os.path.join(OUT, "full512.npz"), **s)
+    print("full512.npz", len(s), "arrays")
+
+
+INIT_CASES = [  # name, constructor kwargs of the generator, of the discriminator, seed
+    ("default", dict(), dict(), 0),
+    ("nd6", dict(num_downs=6), dict(ndf=32), 1),
+    ("small", dict(num_downs=5, ngf=8), dict(ndf=8, n_layers=2), 2),
+]
+
+
+def gen_init(models):
+    """the reference has no custom init (models.py:149-247 rely on reset_parameters), so the same seed must
+    give the same parameters, drawn in the same order: per-tensor sums of the seeded default state_dicts + key order."""
+    s = {}
+    for name, gkw, dkw, seed in INIT_CASES:
+        torch.manual_seed(seed)
+        G = models.UNetGenerator(3, 3, **gkw)
+        D = models.NLayerDiscriminator(6, **dkw)
+        for tag, m in (("g", G), ("d", D)):
+            st = m.state_dict()
+            s[f"init.{name}.{tag}.keys"] = np.array("\n".join(st.keys()))
+            s[f"init.{name}.{tag}.sums"] = np.array([float(v.double().sum()) for v in st.values()], np.float64)
+            s[f"init.{name}.{tag}.abs_sums"] = np.array([float(v.double().abs().sum()) for v in st.values()], np.float64)
+    np.savez_compressed(os.path.join(OUT, "init.npz"), **s)
+    print("init.npz", len(s), "arrays")
+
+
 # -------------------------------------------------------------------------- step
 STEP_CASES = [  # name, num_downs, ngf, ndf, N, H, steps
     ("small", 5, 8, 8, 2, 32, 2),
@@ -461,13 +510,17 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     models, train_gan = import_reference()
-    which = sys.argv[1:] or ["ops", "nets", "full", "step", "siamese", "variants"]      # e.g. `make_golden.py siamese` redoes one file
+    which = sys.argv[1:] or ["ops", "nets", "full", "full512", "init", "step", "siamese", "variants"]      # e.g. `make_golden.py siamese` redoes one file
     if "ops" in which:
         gen_ops()
     if "nets" in which:
         gen_nets(models)
     if "full" in which:
         gen_full(models)
+    if "full512" in which:
+        gen_full512(models)
+    if "init" in which:
+        gen_init(models)
     if "step" in which:
         gen_step(models, train_gan)
     if "siamese" in which:

@@ -354,21 +354,35 @@ def test_data_parallel_two_ranks_on_device(overlap):
     assert r.returncode == 0 and "DP_GPU_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_bench_two_ranks_contract():
-    """bench.py under `torch.distributed.run --nproc-per-node 2` (the driver's launch line): both ranks finish, rank 0
-    prints exactly one JSON line with the whole-job rate and the roofline object."""
+@pytest.mark.parametrize("spelling", ["plain", "torchrun"])
+def test_bench_two_ranks_contract(spelling):
+    """bench.py at two ranks, both ways the driver may start it: plain `python bench.py --gpus 2` (bench.py itself starts
+    torch.distributed.run as a child process before touching a GPU) and under `torch.distributed.run --nproc-per-node 2`:
+    both ranks finish, rank 0 prints exactly one JSON line with the whole-job rate and the roofline object."""
     import json
     import os
+    import subprocess
+    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = _torchrun([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2", "--size", "128"],
-                  {"PFA_BENCH_BACKEND": "gloo", "PFA_BENCH_SHARE_GPU": "1"})
+    argv = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", "2",
+            "--size", "128"]
+    extra = {"PFA_BENCH_BACKEND": "gloo", "PFA_BENCH_SHARE_GPU": "1"}
+    if spelling == "plain":
+        env = dict(os.environ, **extra)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable] + argv, env=env, capture_output=True, text=True, timeout=900)
+    else:
+        r = _torchrun(argv, extra)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 0.02 * out["value"]
+    assert len(out["repeats_ms_per_step"]) == 2
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+    assert any(k["kernel"].startswith("k_wgrad") for k in out["roofline"]["kernels"])
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -614,6 +628,87 @@ def test_config2_step_on_16_copies_equals_step_on_one_pair(precision):
                 # gradient is within rounding of zero
                 off = np.mean(np.abs(got[k] - v) > 0.2 * lr)
                 assert off < (0.02 if precision == "fp32" else 0.10), f"{who} {k}: {off:.2%} of the parameters moved differently"
+
+
+def test_512_forward_fp32_vs_reference(golden):
+    """BASELINE config 4's tile size: default networks at 512x512 against the reference's forward (tests/golden/full512.npz):
+    every map twice as wide as at 256x256, the discriminator's logit map 62x62 (stride-1 patch kernel tiled in x)."""
+    z = golden("full512")
+    G = pfa_gan.UNetGenerator(3, 3).cuda()
+    load(G, fill.fill_state(nets.g_state_shapes(), seed=3))
+    x = torch.from_numpy(fill.uniform("full512.x", (1, 3, 512, 512))).cuda()
+    G.train()
+    with torch.no_grad():
+        y = G(x).cpu().numpy()
+    _digest_ok(z, "full512.g.y", y, ABS, REL)
+    assert_close(y.astype(np.float64).mean(axis=(0, 2, 3)), z["full512.g.y_chan_mean"], 1e-4, 1e-3)
+    D = pfa_gan.NLayerDiscriminator(6).cuda()
+    load(D, fill.fill_state(nets.d_state_shapes(), seed=4))
+    xd = torch.from_numpy(fill.uniform("full512.xd", (1, 6, 512, 512))).cuda()
+    D.train()
+    with torch.no_grad():
+        yd = D(xd).cpu().numpy()
+    assert yd.shape == (1, 1, 62, 62)
+    assert_close(yd, z["full512.d.y"], ABS, REL, "D logits 512")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_config4_step_on_8_copies_equals_step_on_one_pair(precision):
+    """BASELINE config 4 (512x512, 8 pairs per GPU) by the replicated-batch property of the config-2 test: a step on 8
+    copies of one 512x512 pair must give the fake image, losses, BatchNorm means and Adam update of the B=1 step, and
+    runs the launch configurations of that shape (4x the rows per layer of 256x256, 62x62 logits)."""
+    gst = fill.fill_state(nets.g_state_shapes(), seed=41, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(), seed=42, bn_noise=False)
+    a1 = fill.uniform("copies512.a", (1, 3, 512, 512))
+    b1 = fill.uniform("copies512.b", (1, 3, 512, 512))
+    l1, f1, g1, d1 = _one_step(precision, a1, b1, gst, dst)
+    l8, f8, g8, d8 = _one_step(precision, np.repeat(a1, 8, 0), np.repeat(b1, 8, 0), gst, dst)
+    rel = 1e-4 if precision == "fp32" else 1e-2
+    assert_close(l8[0], l1[0], 0, rel, "loss_d")
+    assert_close(l8[1], l1[1], 0, rel, "loss_g")
+    assert np.abs(f8 - f8[:1]).max() == 0.0, "the 8 copies must produce one and the same fake image"
+    if precision == "fp32":
+        assert_close(f8[:1], f1, ABS, REL, "fake_B")
+    else:
+        assert np.abs(f8[:1] - f1).mean() < 1e-2
+    lr = 1e-4
+    for got, want, who in ((g8, g1, "G"), (d8, d1, "D")):
+        for k, v in want.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(got[k]) == int(v), k
+            elif k.endswith("running_var"):
+                continue
+            elif k.endswith("running_mean"):
+                assert_close(got[k], v, 1e-4 if precision == "fp32" else 2e-2, 1e-2, f"{who} {k}")
+            else:
+                off = np.mean(np.abs(got[k] - v) > 0.2 * lr)
+                assert off < (0.02 if precision == "fp32" else 0.10), f"{who} {k}: {off:.2%} of the parameters moved differently"
+
+
+def test_adam_step_count_survives_mixing_graph_replays_and_eager_steps():
+    """A batch of another shape between two hipGraph replays runs eagerly (the short batch collate_fn_skip_none yields when
+    a sample fails to load, dataset.py:13-18).  The eager step moves only the host step count; the next replay must read
+    the same count from the device (Adam's bias corrections): the parameters after graph, ragged eager, graph must equal
+    those of the same three steps run eagerly."""
+    def run(use_graph):
+        torch.manual_seed(9)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda()
+        tr = pfa_gan.GanTrainer(G, D, precision="fp32", use_graph=use_graph, overlap=False)
+        gen = torch.Generator(device="cuda").manual_seed(77)
+        for n in (2, 1, 2, 2):
+            a = torch.rand((n, 3, 64, 64), device="cuda", generator=gen) * 2 - 1
+            b = torch.rand((n, 3, 64, 64), device="cuda", generator=gen) * 2 - 1
+            tr.step(a, b)
+        torch.cuda.synchronize()
+        assert tr.opt_g.steps == 4 and tr.opt_d.steps == 4
+        return tr.opt_g.flat().data.clone(), tr.opt_d.flat().data.clone(), tr.opt_g.m.clone(), tr.opt_g.v.clone()
+
+    eager = run(False)
+    graph = run(True)
+    for e, g, what in zip(eager, graph, ("G parameters", "D parameters", "G first moment", "G second moment")):
+        # 4 steps of lr 1e-4: a step count off by one changes the third update by ~15 % of lr (bias correction 1-0.5^t)
+        assert float((e - g).abs().max()) < 3e-6, what
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

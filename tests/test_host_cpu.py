@@ -163,6 +163,63 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     assert [int(b) for b in r["bn"] if b.dtype == torch.int64] == [int(b) for b in G.buffers() if b.dtype == torch.int64]
 
 
+def test_default_init_matches_reference_seed_for_seed(golden):
+    """the reference never re-initialises (models.py:149-247 rely on reset_parameters), so a user who seeds
+    torch and builds the nets gets the reference's parameters only if these classes create the same sub-modules in the
+    same order: per-tensor sums of the seeded default state_dicts, and the key order, against tests/golden/init.npz
+    (generated from the reference classes)."""
+    from make_golden import INIT_CASES
+    z = golden("init")
+    for name, gkw, dkw, seed in INIT_CASES:
+        torch.manual_seed(seed)
+        G = pfa_gan.UNetGenerator(3, 3, **gkw)
+        D = pfa_gan.NLayerDiscriminator(6, **dkw)
+        for tag, m in (("g", G), ("d", D)):
+            st = m.state_dict()
+            assert list(st.keys()) == str(z[f"init.{name}.{tag}.keys"]).split("\n"), (name, tag)
+            sums = np.array([float(v.double().sum()) for v in st.values()])
+            asums = np.array([float(v.double().abs().sum()) for v in st.values()])
+            np.testing.assert_array_equal(sums, z[f"init.{name}.{tag}.sums"])
+            np.testing.assert_array_equal(asums, z[f"init.{name}.{tag}.abs_sums"])
+
+
+def _dp_skip_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        torch.manual_seed(100)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8)
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8)
+        og = torch.optim.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        od = torch.optim.Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.999))
+        batches = [dict(image1=torch.from_numpy(fill.uniform(f"sk.a{i}", (2, 3, 32, 32), seed=rank)),
+                        image2=torch.from_numpy(fill.uniform(f"sk.b{i}", (2, 3, 32, 32), seed=rank))) for i in range(3)]
+        if rank == 1:
+            batches[1] = None           # what collate_fn_skip_none yields when every sample of the batch failed to load
+        pfa_gan.train_gan_one_epoch(G, D, batches, og, od, process_group=dist.group.WORLD)
+        steps = torch.tensor([og.state[next(iter(G.parameters()))]["step"].item()])
+        allsteps = [torch.empty_like(steps) for _ in range(world)]
+        dist.all_gather(allsteps, steps)
+        flat = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            torch.save(dict(steps=[int(t) for t in allsteps], same=bool(torch.equal(gathered[0], gathered[1]))), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_skips_a_missing_batch_on_every_rank(tmp_path):
+    """One rank's batch collates to None (dataset.py:13-18): every rank skips that iteration instead of one rank entering
+    the gradient all-reduces alone (a hang until the collective times out)."""
+    out = str(tmp_path / "skip.pt")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_dp_skip_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out, weights_only=False)
+    assert r["steps"] == [2, 2], r
+    assert r["same"], "replicas diverged"
+
+
 def test_siamese_unet_dropin_matches_reference_golden(golden):
     """`from models import SiameseUNet` (reference train.py:16, evaluate.py:12) resolves to a plain-torch module with the
     reference's state_dict keys (in order), seeded default init and train / eval arithmetic (tests/golden/siamese.npz,
