@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of cpu_baseline_isolated
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer = BASELINE config 5: generator-only eval forward (generate_synthetic_data.py:55-68), tiles/s")
     return ap.parse_args()
@@ -172,6 +173,22 @@ def _cpu_info():
     except OSError:
         pass
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) bounds what the threads can really use
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        usable = max(1, min(usable, int(quota + 0.5)))
     return model, len(phys) or None, os.cpu_count(), usable
 
 
@@ -212,14 +229,18 @@ def cpu_baseline(size, budget_s, infer=False):
 
     # thread count: all usable cores unless fewer are measurably faster (small convolutions on
     # very many threads spend their time in the thread pool)
-    cands = sorted({usable, min(usable, 64), min(usable, 32), min(usable, 16)}, reverse=True)
+    cands = sorted({min(usable, 16), min(usable, 32), min(usable, 64), usable})      # ascending: stop when more threads lose
     best_t, best_s = cands[0], None
+    probed = []
     for t in cands:
         torch.set_num_threads(t)
         run(4, 1)                                     # warm-up at this thread count
         s = run(4, 1)
+        probed.append(t)
         if best_s is None or s < best_s:
             best_t, best_s = t, s
+        elif s > 1.1 * best_s:
+            break
         if time.perf_counter() - t_start > 0.4 * budget_s:
             break
     torch.set_num_threads(best_t)
@@ -240,7 +261,27 @@ def cpu_baseline(size, budget_s, infer=False):
                 torch=torch.__version__,
                 sample=f"pfa_gan {what}, default nets, {size}x{size}, fp32, batch "
                        f"{' and '.join(str(b) for b in sorted(res))}: 1 warm-up + 3 timed steps each; value = batch {b_best}; "
-                       f"threads probed {cands[:cands.index(best_t) + 1] if best_t in cands else cands}, fastest {best_t}")
+                       f"threads probed {probed}, fastest {best_t}")
+
+
+def cpu_baseline_isolated(size, budget_s, infer=False):
+    """cpu_baseline() in a child process with a hard time limit: the CPU leg can never hang or starve the GPU process
+    (its thread pools stay out of this process), and the JSON line is printed whatever happens to it."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(size), "--cpu-seconds", str(budget_s),
+           "--mode", "infer" if infer else "train"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3 * budget_s + 60)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return dict(value=None, unit="tiles/s" if infer else "img-pairs/s", cores=None, kind="port",
+                    sample=f"cpu_baseline child failed (rc {r.returncode}): {r.stderr[-300:]}")
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="tiles/s" if infer else "img-pairs/s", cores=None, kind="port",
+                    sample=f"cpu_baseline child exceeded {3 * budget_s + 60:.0f} s")
 
 
 # ----------------------------------------------------------------------------------------------------- inference (config 5)
@@ -299,12 +340,15 @@ def infer_main(args):
         out["roofline"] = _roofline_object(_timed_kernels(lib, _lib), n, peak, flop_tile * args.batch,
                                            f"infer_b{args.batch}_{args.size}_{args.precision}")
     if not args.no_cpu_baseline and args.size == 256:
-        out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds, infer=True)
+        out["cpu_baseline"] = cpu_baseline_isolated(args.size, args.cpu_seconds, infer=True)
     print(json.dumps(out), flush=True)
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.size, args.cpu_seconds, infer=args.mode == "infer")), flush=True)
+        return
     if args.mode == "infer":
         return infer_main(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -407,7 +451,7 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline and args.size == 256:
-            out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline_isolated(args.size, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -47,6 +47,9 @@ static inline int pfa_knob(int i) { return g_knob[i].load(std::memory_order_rela
 bool pfa_timing_begin(hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);      // false: timing is off (or the store is full)
 void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk);
 
+extern void* g_pfa_dbgbuf;              // pfa_set_debug_buffer: device memory a kernel may write developer stamps to
+extern size_t g_pfa_dbgbuf_bytes;
+
 // csrc/conv_patch.hip: stride-1 convolution forward with the input patch kept in LDS (dispatched by pfa_gather_gemm)
 bool pfa_conv_s1_patch_ok(int grad, int nb, int hin, int win, int cin, int n, int splitk, int* stat_tiles);
 int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float* slab, int splitk, float* psum, float* psq,

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pfa_last_error_string": (c_char_p, []),
     "pfa_launch_count": (c_uint64, []),
     "pfa_set_knob": (c_int, [c_int, c_int]),
+    "pfa_set_debug_buffer": (c_int, [c_void_p, c_size_t]),
     "pfa_last_gather_kernel": (c_char_p, []),
     "pfa_gather_timing": (c_int, [c_int]),
     "pfa_gather_timing_count": (c_int, []),

@@ -97,11 +97,16 @@ class Ctx:
     def __init__(self, device):
         self.device = device
         self._t = {}
+        self._retired = []      # replaced buffers stay alive: a captured hipGraph may still launch kernels on them
         self.v = {}
 
     def buf(self, name, shape, dtype):
         t = self._t.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            if t is not None:
+                # a batch of another shape (a ragged last batch between two hipGraph replays): the graph keeps launching
+                # on the old buffer, so it must not go back to the allocator; shapes alternate at most a few times
+                self._retired.append(t)
             t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
             self._t[name] = t
         return t

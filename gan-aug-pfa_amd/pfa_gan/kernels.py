@@ -63,10 +63,13 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self._bufs = {}
+        self._retired = []      # outgrown buffers stay alive: a captured hipGraph may still launch kernels on them
 
     def get(self, name, numel, dtype=torch.float32):
         buf = self._bufs.get(name)
         if buf is None or buf.numel() < numel or buf.dtype != dtype:
+            if buf is not None:
+                self._retired.append(buf)
             buf = torch.empty(max(int(numel), 1), dtype=dtype, device=self.device)
             self._bufs[name] = buf
         return buf

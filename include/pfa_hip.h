@@ -58,13 +58,19 @@ uint64_t pfa_launch_count(void);
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
  * 5 = no K-group pairs, 6 = pairs from four slices on);
- * id 3: stride-1 convolutions (forward and input gradient) on the input-patch kernel (conv_patch.hip): 0 = launches with >= 128 workgroups,
- * 1 = never, 2 = whenever the geometry fits;
+ * id 3: the input-patch kernels (conv_patch.hip: stride-1 convolutions, forward and input gradient; conv_patch2.hip: stride-2
+ * convolutions and transposed convolutions): 0 = launches large enough to fill the chip, 1 = never, 2 = whenever the geometry
+ * fits, 3 = the stride-1 kernel only;
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
- * of 256-row tiles for the ring tile (0 = default); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
+ * of 256-row tiles for the ring tile, and of workgroups a stride-2 patch launch wants before it narrows its channel tile
+ * or slices K (0 = defaults); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
  * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half). */
 int pfa_set_knob(int id, int value);
+/* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write four shader-clock
+ * stamps per workgroup (entry, first fragments in registers, K loop done, stores accepted) as uint64[workgroups][4].
+ * Never changes a result; off by default. */
+int pfa_set_debug_buffer(void* dev, size_t bytes);
 /* Kernel instantiation the calling thread's most recent pfa_gather_gemm launched, e.g. "k_gather_gemm<bf16,256,128,4,2,3>"
  * (tile rows, tile columns, wave grid, K-loop variant): lets a profiler script attribute a launch to a kernel name. */
 const char* pfa_last_gather_kernel(void);

@@ -182,6 +182,75 @@ def test_conv_s1_patch_kernel_input_gradient(case, ws):
     close(from_nhwc(outs[0], ci), from_nhwc(outs[1], ci), dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
 
 
+PATCH2_CASES = [  # name, kind, N, cin parts, H, W (input), Co, K slices, knob 6 (workgroups wanted), kernel, output split
+    ("tconv_cat", "tconv", 2, [64, 64], 9, 33, 128, 1, 1, "k_conv_patch2<tconv,128,8x32>", None),       # ragged 8x32 tiles, virtual concat
+    ("tconv_16", "tconv", 2, [128], 16, 16, 64, 1, 0, "k_conv_patch2<tconv,64,16x16>", None),          # 16x16 tile, 64-channel tile
+    ("tconv_17", "tconv", 1, [64], 17, 20, 128, 1, 1, "k_conv_patch2<tconv,128,16x16>", None),         # ragged 16x16 tiles
+    ("tconv_sliced", "tconv", 2, [128, 64], 16, 16, 64, 3, 0, "k_conv_patch2<tconv,64,16x16>", None),  # three K slices -> slab + finish
+    ("tconv_wide", "tconv", 1, [64], 8, 70, 64, 1, 0, "k_conv_patch2<tconv,64,8x32>", None),           # three tile columns
+    ("conv_e2", "conv", 1, [64], 34, 70, 128, 1, 1, "k_conv_patch2<conv_s2,128,8x32>", None),          # out 17x35: ragged both ways
+    ("conv_16", "conv", 2, [128], 32, 32, 192, 1, 0, "k_conv_patch2<conv_s2,64,16x16>", None),         # 3 n-tiles of 64
+    ("conv_split_out", "conv", 2, [64], 32, 64, 128, 1, 1, "k_conv_patch2<conv_s2,128,8x32>", 64),    # two outputs (decoder dgrad)
+    ("conv_sliced", "conv", 1, [128], 32, 32, 64, 4, 0, "k_conv_patch2<conv_s2,64,16x16>", None),      # 8 super-steps in 4 slices
+    ("conv_cat", "conv", 1, [64, 128], 36, 32, 64, 1, 0, "k_conv_patch2<conv_s2,64,16x16>", None),     # two sources of unequal width
+]
+
+
+@pytest.mark.parametrize("case", PATCH2_CASES, ids=[c[0] for c in PATCH2_CASES])
+def test_conv_patch2_kernels(case, ws):
+    """Stride-2 convolutions and transposed convolutions on the patch kernels of conv_patch2.hip (pfa_set_knob(3, 2) routes
+    launches this small there): the oracle, the statistics contract, and the implicit GEMM's result (knob 3 = 1) up to
+    the order of the float32 sums - ragged tiles, both tile shapes, both channel tiles, K slices, the virtual concat
+    and the split output of a decoder input gradient."""
+    name, kind, n, cins, h, w, co, slices, knob6, kernel_want, n1 = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".x", (n, ci, h, w)), dtype)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    if kind == "conv":
+        wt = rnd(fill.uniform(name + ".w", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        want = ops.conv2d_fwd(x, wt, None, 2)
+        wsh, _ = shadows(wt, dtype, cparts=[(c, c) for c in cins], want=("same",))
+        mode, grid = K.CONV_S2, (n,) + want.shape[2:]
+    else:
+        wt = rnd(fill.uniform(name + ".w", (ci, co, 4, 4), -0.25, 0.25), dtype)
+        want = ops.convT2d_fwd(x, wt, None)
+        _, wsh = shadows(wt, dtype, want=("tr",))
+        mode, grid = K.TCONV_S2, (n, h, w)
+    lib = _lib.lib()
+    res, stats = [], []
+    for knob3 in (2, 1):
+        shape = (n,) + want.shape[2:]
+        outs = [torch.full(shape + (co,), 7.0, dtype=dtype, device="cuda")] if n1 is None else \
+            [torch.full(shape + (n1,), 7.0, dtype=dtype, device="cuda"), torch.full(shape + (co - n1,), 7.0, dtype=dtype, device="cuda")]
+        lib.pfa_set_knob(3, knob3)
+        lib.pfa_set_knob(6, knob6)
+        try:
+            st = K.gather_gemm(mode, srcs, wsh, co, outs, grid, ws, stats=n1 is None, splitk=slices)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(3, 0)
+            lib.pfa_set_knob(6, 0)
+        assert (kernel == kernel_want) if knob3 == 2 else kernel.startswith("k_gather_gemm"), kernel
+        got = from_nhwc(outs[0], outs[0].shape[3]) if n1 is None else \
+            np.concatenate([from_nhwc(outs[0], n1), from_nhwc(outs[1], co - n1)], axis=1)
+        res.append(got)
+        if st is not None:
+            psum, psq, nt = st
+            torch.cuda.synchronize()
+            stats.append((psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy(),
+                          psq[: nt * co].view(nt, co).double().sum(0).cpu().numpy()))
+    close(res[0], want, dtype, name)
+    close(res[0], res[1], dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
+    if stats:
+        close(stats[0][0], want.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
+              scale=np.abs(want).sum(axis=(0, 2, 3)).max())
+        close(stats[0][1], (want.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
+
+
 CONVT_FWD = [  # name, N, cin parts, H, W, Co, bias, act, splitk
     ("d7_like", 2, [16], 1, 1, 16, False, K.ACT_NONE, None),
     ("mid_cat", 2, [16, 16], 4, 4, 8, False, K.ACT_NONE, None),
@@ -282,6 +351,8 @@ AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs, K slices
     ("dec", "tconv", 2, [64, 64], 8, 8, 48, False, 1),             # transposed conv, virtual concat, one output
     ("enc_sliced", "conv", 2, [64], 8, 8, 128, True, 4),           # K-sliced: the affine map moves to the finish pass
     ("dec_sliced", "tconv", 2, [64, 64], 4, 4, 64, False, 3),
+    ("p2_enc", "conv", 2, [64], 32, 32, 128, True, 1),              # p2_*: on the patch kernels (bf16, pfa_set_knob(3, 2))
+    ("p2_dec", "tconv", 2, [64, 64], 16, 16, 64, False, 1),
 ]
 
 
@@ -316,7 +387,15 @@ def test_affine_epilogue(case, dtype, ws):
     outs = [torch.full((n, ho, wo, cp), 7.0, dtype=dtype, device="cuda") for _ in range(2 if dual else 1)]
     sc, sh = torch.from_numpy(scale).cuda(), torch.from_numpy(shift).cuda()
     act1 = K.ACT_LRELU if dual else K.ACT_RELU
-    K.gather_gemm(gmode, srcs, wdev, co, outs, grid, ws, act=act1, splitk=slices, affine=(sc, sh, K.ACT_RELU))
+    force = name.startswith("p2_")
+    if force:
+        _lib.lib().pfa_set_knob(3, 2)
+    try:
+        K.gather_gemm(gmode, srcs, wdev, co, outs, grid, ws, act=act1, splitk=slices, affine=(sc, sh, K.ACT_RELU))
+        kernel = _lib.lib().pfa_last_gather_kernel().decode()
+    finally:
+        _lib.lib().pfa_set_knob(3, 0)
+    assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
     close(from_nhwc(outs[0], co), ops.leaky_relu(y) if dual else ops.relu(y), dtype, name + " out1", scale=np.abs(y).max())
     if dual:
         close(from_nhwc(outs[1], co), ops.relu(y), dtype, name + " out2", scale=np.abs(y).max())
@@ -334,6 +413,10 @@ FUSED_BWD_CASES = [  # name, N, cin, H, W, Co (columns), K slices, BatchNorm, se
     ("act_sliced", 2, [64], 8, 8, 64, 2, False, False, False),
     ("two_outputs_sliced", 2, [64], 8, 8, 128, 4, True, False, True),    # [plain 64 | fused 64] like the decoder's dgrad
     ("two_outputs", 2, [64], 16, 16, 128, 1, True, False, True),
+    # p2_*: 16x16 output maps, routed to the patch kernels of conv_patch2.hip in bf16 (pfa_set_knob(3, 2)): the shared epilogue
+    ("p2_bn_g2", 2, [64], 32, 32, 128, 1, True, True, False),
+    ("p2_two_outputs", 2, [64], 32, 32, 128, 1, True, False, True),
+    ("p2_act_sliced", 2, [128], 32, 32, 64, 2, False, False, False),
 ]
 
 
@@ -373,7 +456,15 @@ def test_fused_backward_epilogue(case, dtype, ws):
     if bn:
         spec.update(scale=dev(scale), shift=dev(shift), mean=dev(mean), invstd=dev(invstd))
     before = _lib.launch_count()
-    st = K.gather_gemm(K.CONV_S2, srcs, wsh, co, outs, (n, ho, wo), ws, splitk=slices, fuse=spec)
+    force = name.startswith("p2_")
+    if force:
+        _lib.lib().pfa_set_knob(3, 2)
+    try:
+        st = K.gather_gemm(K.CONV_S2, srcs, wsh, co, outs, (n, ho, wo), ws, splitk=slices, fuse=spec)
+        kernel = _lib.lib().pfa_last_gather_kernel().decode()
+    finally:
+        _lib.lib().pfa_set_knob(3, 0)
+    assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
     launches = _lib.launch_count() - before
     assert launches == (2 if slices > 1 else 1)
     amax = np.abs(g).max()

@@ -1,0 +1,48 @@
+"""Where a stride-2 patch launch spends its time: four shader-clock stamps per workgroup (pfa_set_debug_buffer) on the
+config-2 shapes -> median cycles of prologue / K loop / epilogue, the spread of workgroup start times, and the launch's
+event time."""
+import os, sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
+import torch
+from pfa_gan import kernels as K, _lib
+B = 16
+dt = torch.bfloat16
+ws = K.Workspace(torch.device('cuda'))
+def T(*shape): return torch.randn(shape, device='cuda', dtype=torch.float32).to(dt)
+L = [
+ ("e2/c2 fwd", K.CONV_S2, (128, 128, [64]), 128, (64, 64)),
+ ("e3/c3 fwd", K.CONV_S2, (64, 64, [128]), 256, (32, 32)),
+ ("d2 dgrad",  K.CONV_S2, (128, 128, [64]), 256, (64, 64)),
+ ("d3 dgrad",  K.CONV_S2, (64, 64, [128]), 512, (32, 32)),
+ ("d4 dgrad",  K.CONV_S2, (32, 32, [256]), 1024, (16, 16)),
+ ("d2 fwd",    K.TCONV_S2, (64, 64, [128, 128]), 64, (64, 64)),
+ ("d3 fwd",    K.TCONV_S2, (32, 32, [256, 256]), 128, (32, 32)),
+ ("d4 fwd",    K.TCONV_S2, (16, 16, [512, 512]), 256, (16, 16)),
+ ("e2/c2 dgrad", K.TCONV_S2, (64, 64, [128]), 64, (64, 64)),
+ ("e3/c3 dgrad", K.TCONV_S2, (32, 32, [256]), 128, (32, 32)),
+]
+lib = _lib.lib()
+buf = torch.zeros(8192 * 4, dtype=torch.int64, device='cuda')
+print(f"{'layer':14s} {'wgs':>5s} {'event us':>9s} | cycles (median over workgroups): prologue   loop  epilogue  total | start spread  end spread (cycles)")
+for name, mode, (h, w, cs), n, (hq, wq) in L:
+    srcs = [T(B, h, w, c) for c in cs]
+    wgt = T(n, 16, sum(cs))
+    ho, wo = (2 * hq, 2 * wq) if mode == K.TCONV_S2 else (hq, wq)
+    o = torch.empty((B, ho, wo, n), device='cuda', dtype=dt)
+    stats = os.environ.get("PFA_STATS") == "1"
+    for _ in range(3):
+        K.gather_gemm(mode, srcs, wgt, n, [o], (B, hq, wq), ws, stats=stats)
+    torch.cuda.synchronize()
+    buf.zero_()
+    lib.pfa_set_debug_buffer(buf.data_ptr(), buf.numel() * 8)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    K.gather_gemm(mode, srcs, wgt, n, [o], (B, hq, wq), ws, stats=stats)
+    e1.record(); torch.cuda.synchronize()
+    lib.pfa_set_debug_buffer(None, 0)
+    st = buf.view(-1, 4).cpu()
+    st = st[st[:, 3] != 0]
+    d = st.double()
+    pro, loop, epi, tot = (d[:, 1] - d[:, 0]).median(), (d[:, 2] - d[:, 1]).median(), (d[:, 3] - d[:, 2]).median(), (d[:, 3] - d[:, 0]).median()
+    print(f"{name:14s} {st.shape[0]:5d} {e0.elapsed_time(e1)*1e3:9.1f} | {pro:10.0f} {loop:7.0f} {epi:8.0f} {tot:7.0f} | "
+          f"{(d[:, 0].max() - d[:, 0].min()):10.0f} {(d[:, 3].max() - d[:, 3].min()):10.0f}   span {(d[:, 3].max() - d[:, 0].min()):8.0f}")
