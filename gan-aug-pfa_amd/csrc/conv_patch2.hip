@@ -10,33 +10,43 @@
 //   CONV_S2   out(qy, qx) = sum over the four input parity planes (ey, ex) of sum_{a,b} in(2(qy+a)-1+ey, 2(qx+b)-1+ex)
 //             * w[(2a+ey)*4 + 2b+ex]                                          - one patch per chunk AND plane.
 // A "super-step" is one such 2x2-tap convolution over one 64-channel chunk: the workgroup stages its (TY+1) x (TX+1)
-// input pixels ONCE (LDS-DMA, 144 bytes per pixel: 16 consecutive pixels fall on 16 distinct bank groups, a tap shift is a
-// wave-uniform address offset) and walks the four taps inside LDS; only the weight tile of a tap step (BN rows x 128 B)
-// streams through a 3-slot ring.  DMA bytes per FLOP: 1/157 against 1/87 for the ring tile, and every input pixel is
-// fetched once per workgroup instead of four times.
+// input pixels ONCE (LDS-DMA, 144 bytes per pixel: a tap shift is a constant address offset) and walks the four taps
+// inside LDS; only the weight tile of a tap step (BN rows x 128 B) streams through a 4-slot ring.  DMA bytes per FLOP:
+// 1/157 against 1/87 for the ring tile, and every input pixel is fetched once per workgroup instead of four times.
 //
-// K loop: ONE barrier per tap step, no phases.  The fragments of step i+1 are read from LDS into a second register set
-// BETWEEN the MFMAs of step i (one ds_read_b128 per two MFMAs: the LDS read pipe and the MFMA pipe of a SIMD run side by
-// side, nothing waits for a read issued right behind a barrier) and retired by one lgkmcnt(0) at the end of the step.
-// Because a stage's fragments are in registers a full step before its MFMAs, its ring slot is refilled as soon as the
-// step begins: two weight stages and up to two patch pieces are in flight across every barrier (counted vmcnt).
-//   step i:  barrier | DMA W(i+3) -> slot i%3, patch pieces of a later super-step | 32 MFMAs(i) interleaved with the 16
-//            reads of stage i+1 | lgkmcnt(0) | vmcnt(what this step issued)
-//   RAW: data issued in step k is waited for at the end of step k+1 by every wave, i.e. visible after barrier k+2; stage
-//        i+1 (issued in step i-2) is read during step i.  Patch S (steps 4S..4S+3, first read during step 4S-1) is
-//        issued in steps 4S-5..4S-3.
-//   WAR: slot i%3 was read during step i-1 (retired before barrier i); patch buffer S%2 was last read during step 4S-6
-//        (the reads of step 4S-5), retired before barrier 4S-5.
+// MFMA 32x32x16 (a wave = 64 positions x BN/2 channels = 2 x {2|1} tiles of 32x32): per FLOP it holds the SIMD's issue
+// port half as long as 16x16x32 - the K loop of the first version (16x16x32) was bound by instruction issue, not by the
+// matrix pipe: 1750 cycles per step against 1024 of MFMA - and all 16 lanes of a ds_read_b128 lane group then read the
+// SAME k-chunk, so 32 consecutive 144-byte pixels fall on distinct bank slots (with 16x16x32 a lane group mixes two
+// k-chunks, which collide at that pitch: every activation read took two passes, measured as ~137 B/clk/CU).
+//
+// K loop: ONE barrier per tap step, and ONE fragment register set: a step is four k-steps (16 channels each); right after
+// the MFMAs of k-step s have been issued, the fragments of k-step s of the NEXT tap step are read into the registers they
+// just consumed (ds_read_b128, retired by counted lgkmcnt one full step later: LDS latency never shows, nothing waits for a
+// read issued behind a barrier).  The loop is unrolled over the 8 (patch buffer, tap) combinations so that every LDS read
+// address is a per-lane register plus an immediate: no address arithmetic in the loop.
+// Because a stage's fragments are read a full step before its MFMAs, its ring slot is free early: two weight stages and
+// up to two patch pieces are in flight across every barrier (counted vmcnt).
+//   step i:  barrier | per k-step s: lgkmcnt(3 k-steps) - 4 MFMAs(i, s) - 4 reads(i+1, s) - part of the DMA (W(i+3) ->
+//            slot (i+3)%4, patch pieces of a later super-step) | vmcnt(what this step issued)
+//   RAW: data issued in step k is waited for at the end of step k+1 by every wave, i.e. visible after barrier k+2; the
+//        fragments of stage i+1 (issued in step i-2) are read during step i.  Patch S (steps 4S..4S+3, first read during
+//        step 4S-1) is issued in steps 4S-4 and 4S-3, three pieces each.
+//   WAR: slot (i+3)%4 held stage i-1, whose reads (issued during step i-2) every wave retired during step i-1, i.e.
+//        before barrier i; patch buffer S%2 was last read by the fragments of step 4S-5, issued during step 4S-6 and
+//        retired during step 4S-5, i.e. before barrier 4S-4.
 #include "patch_epilogue.h"
 
 #include <type_traits>
 
 namespace {
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
 constexpr int PSTRIDE = 144;                      // bytes per patch pixel: 128 + one unused 16-byte piece
 constexpr int PPASS = 6;                          // 6 x 512 lanes x 16 B = 341 pixel slots >= 9x33 = 297, 17x17 = 289
 constexpr int PATCH_BYTES = PPASS * 512 * 16;     // 49,152
-constexpr int W_SLOTS = 3;
+constexpr int W_SLOTS = 4;
 
 struct Patch2K {
     GatherK g;
@@ -47,25 +57,36 @@ struct Patch2K {
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Fragment read INTO the register that held the same fragment of the previous step ("+v": the allocator must reuse it -
+// with a fresh output per read it spreads the fragments of the unrolled steps over different registers and pays ~70
+// v_mov per step to line them up again at the loop's back edge).  The MFMA that consumed the old value was issued before
+// this instruction and has read its A/B operands long before the LDS data (>= 64 cycles away) lands.
+template <int OFF> __device__ __forceinline__ void lds_rd(unsigned addr, bf16x8& v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF));
+}
 
 // MODE 0 = PFA_TCONV_S2, 1 = PFA_CONV_S2.  TILE16: 16 x 16 position tile instead of 8 x 32.  BN: 128 or 64 output channels.
 // ABL: ablation bits of a diagnostic instantiation (1 no MFMA, 2 no fragment reads, 4 no DMA - results are wrong); 0 in every
-// instantiation the library launches by default.
+// instantiation the library launches.
 template <int MODE, int BN, int TILE16, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_patch2(const Patch2K q) {
     typedef bf16_t T;
     constexpr int TY = TILE16 ? 16 : 8, TX = TILE16 ? 16 : 32;
     constexpr int PH = TY + 1, PW = TX + 1, PSLOTS = PH * PW;
-    constexpr int FN = BN / 32, FM = 4;                    // 4 x 2 waves: 64 positions x BN/2 channels per wave
+    constexpr int FN = BN / 64, FM = 2;                    // 4 x 2 waves: 64 positions x BN/2 channels per wave, 32x32 tiles
+    constexpr int KS = 4;                                  // MFMA k-steps (16 channels) per 64-channel chunk
     constexpr int W_BYTES = BN * 128, WP = BN / 64;        // weight tile of a step, DMA pieces per wave
-    constexpr int NREAD = 2 * (FN + FM), NMFMA = 2 * FN * FM;
+    constexpr int NREAD = KS * (FN + FM), NMFMA = KS * FN * FM;
+    constexpr int WBASE = 2 * PATCH_BYTES;
     static_assert(PSLOTS * 9 <= PPASS * 512, "patch does not fit its buffer");
+    static_assert(3 * W_BYTES < 65536 && PATCH_BYTES + (PW + 1) * PSTRIDE + 128 < 65536, "ds offset field");
     const GatherK& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
-    const int lrow = lane & 15, kk = lane >> 4;
+    const int lr = lane & 31, lh = lane >> 5;
     // work list: n-tile fastest (the workgroups that share a patch sit next to each other on one XCD), then K slice,
     // parity class, tile, image
     unsigned wid = xcd_remap(blockIdx.x, q.nwg);
@@ -84,7 +105,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     stamp(0);
 
     // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding
-    int ppix[PPASS];             // source pixel index (MODE 1: of plane (0,0); plane (ey,ex) adds ey*ws + ex)
+    int ppix[PPASS];             // source pixel * 8 + piece (MODE 1: of plane (0,0); plane (ey,ex) adds (ey*ws + ex) * 8)
     unsigned pok = 0;            // validity bits: MODE 0 bit j; MODE 1 bit plane*8 + j
 #pragma unroll
     for (int j = 0; j < PPASS; ++j) {
@@ -94,7 +115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (MODE == 0) {
             const int iy = qy0 + py - 1 + sy, ix = qx0 + px - 1 + sx;
             const bool ok = inb && (unsigned)iy < (unsigned)p.hs && (unsigned)ix < (unsigned)p.ws;
-            ppix[j] = ((img * p.hs + iy) * p.ws + ix) * 8 + (g & 7);      // pixel * 8 + piece: one multiply by C/8 later
+            ppix[j] = ((img * p.hs + iy) * p.ws + ix) * 8 + (g & 7);
             pok |= ok ? (1u << j) : 0u;
         } else {
             const int iy = 2 * (qy0 + sy) - 1, ix = 2 * (qx0 + sx) - 1;
@@ -123,8 +144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
             const bool ok = (pok >> ((MODE == 0 ? 0 : pl * 8) + j)) & 1u;
-            // element offset = pixel * C + cc * 64 + g * 8  =  ((pixel*8 + g) + plane) ... with C = 8 * c8:
-            const int pg = ppix[j] + pladd;                  // pixel * 8 + g
+            const int pg = ppix[j] + pladd;                  // pixel * 8 + piece
             const int pix = pg >> 3, g = pg & 7;
             const unsigned off = (unsigned)((pix * c8 * 8 + cc * 64 + g * 8) * 2);
             const char* gp = ok ? base + off : zero;
@@ -137,149 +157,187 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     unsigned woff[WP];
 #pragma unroll
     for (int i = 0; i < WP; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * p.ctot + wgc * 8) * 2);
-    auto stage_w = [&](int step) {                            // step of this slice: super-step step >> 2, tap step & 3
+    auto stage_w_piece = [&](int step, int i) {               // step of this slice: super-step step >> 2, tap step & 3
         const int gs = ss0 + (step >> 2), t = step & 3, a = t >> 1, b = t & 1;
         int chunk, widx;
         if (MODE == 0) { chunk = gs; widx = (3 - py - 2 * a) * 4 + (3 - px - 2 * b); }
         else { chunk = gs >> 2; const int pl = gs & 3; widx = (2 * a + (pl >> 1)) * 4 + 2 * b + (pl & 1); }
-        char* wb = smem + 2 * PATCH_BYTES + (step % W_SLOTS) * W_BYTES;
+        char* wb = smem + WBASE + (step & (W_SLOTS - 1)) * W_BYTES;
+        const char* gp = p.w + woff[i] + (unsigned)((widx * p.ctot + chunk * 64) * 2);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    auto stage_w = [&](int step) {
 #pragma unroll
-        for (int i = 0; i < WP; ++i) {
-            const char* gp = p.w + woff[i] + (unsigned)((widx * p.ctot + chunk * 64) * 2);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < WP; ++i) stage_w_piece(step, i);
     };
 
-    f32x4 acc[FN][FM];
+    f32x16 acc[FN][FM];
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
-        for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < FM; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    // activation fragment b of this wave = 16 consecutive positions of one tile row
+    // ---- fragment addresses.  32x32x16 operands: lane (lr = lane & 31, lh = lane >> 5) supplies row lr, k = 16 s + 8 lh .. +7
+    // of k-step s, i.e. the 16-byte chunk 2 s + lh of the row's 128 bytes.
+    // Activation tile b of this wave = 32 positions: 8x32 tile: tile row wm*2 + b, columns lr; 16x16 tile: tile rows
+    // wm*4 + 2b + (lr >> 4), column ((lr & 15) - (lr >> 4) * (PW & 15)) & 15 - the second row rotated by the row pitch, so that
+    // the 32 pixel slots are distinct mod 16 (conflict-free ds_read_b128: 16 lanes of a group, one k-chunk, pitch 9 * 16 B).
     const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-    int frow[FM], fcol[FM];
-    unsigned abyte[FM];
+    int tpos[FM];                // tile-local position (row-major TY x TX) of this lane's row of tile b
+    unsigned abyte[FM];          // its patch byte address at tap (0, 0), patch buffer 0, k-step 0
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
-        frow[b] = TILE16 ? wm * 4 + b : wm * 2 + (b >> 1);
-        fcol[b] = TILE16 ? 0 : (b & 1) * 16;
-        abyte[b] = lds0 + (frow[b] * PW + fcol[b] + lrow) * PSTRIDE + kk * 16;
+        int trow_, tcol_;
+        if (TILE16) { trow_ = wm * 4 + 2 * b + (lr >> 4); tcol_ = ((lr & 15) - (lr >> 4) * (PW & 15)) & 15; }
+        else { trow_ = wm * 2 + b; tcol_ = lr; }
+        tpos[b] = trow_ * TX + tcol_;
+        abyte[b] = lds0 + (trow_ * PW + tcol_) * PSTRIDE + lh * 16;
     }
-    unsigned wfb[2];
-    {
-        const unsigned sw = (lrow >> 1) & 7;
+    unsigned wadr[FN][KS];       // weight fragment (channel tile a, k-step s): row wn*BN/2 + a*32 + lr, swizzled chunk
 #pragma unroll
-        for (int h = 0; h < 2; ++h) wfb[h] = lds0 + 2 * PATCH_BYTES + (wn * (BN / 2) + lrow) * 128 + (((kk + 4 * h) ^ sw) << 4);
+    for (int a = 0; a < FN; ++a) {
+        const int row = wn * (BN / 2) + a * 32 + lr;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) wadr[a][s2] = lds0 + WBASE + row * 128 + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 4);
     }
-    struct Frags { bf16x8 w[2][FN], a[2][FM]; };
-    // read r (0 .. NREAD-1) of a step: k-half h = r / (FN+FM), then the FN weight fragments, then the FM activation ones
-    auto read_one = [&](Frags& f, int step, int r) {
-        const int t = step & 3, S = step >> 2;
-        const unsigned tb = (S & 1) * PATCH_BYTES + ((t >> 1) * PW + (t & 1)) * PSTRIDE;
-        const unsigned rb = (step % W_SLOTS) * W_BYTES;
-        const int h = r / (FN + FM), e = r - h * (FN + FM);
-        if (e < FN) {
-            const unsigned ad = wfb[h] + rb;
-            if (e == 0) f.w[h][0] = lds_read16<bf16x8, 0>(ad);
-            else if (e == 1) f.w[h][1] = lds_read16<bf16x8, 2048>(ad);
-            else if (e == 2) f.w[h][e] = lds_read16<bf16x8, 4096>(ad);
-            else f.w[h][e] = lds_read16<bf16x8, 6144>(ad);
-        } else {
-            const int b = e - FN;
-            if (h == 0) f.a[0][b] = lds_read16<bf16x8, 0>(abyte[b] + tb);
-            else f.a[1][b] = lds_read16<bf16x8, 64>(abyte[b] + tb);
-        }
+    struct Frags { bf16x8 w[FN][KS], a[FM][KS]; };
+    // read r (0 .. NREAD-1) of the step with compile-time (patch buffer PB, tap TP, weight slot WS): k-step major, the FN
+    // weight fragments then the FM activation ones
+    auto read_one = [&](Frags& f, auto pb_, auto tp_, auto ws_, auto r_) {
+        constexpr int PB = decltype(pb_)::value, TP = decltype(tp_)::value, WS = decltype(ws_)::value, R = decltype(r_)::value;
+        constexpr int S2 = R / (FN + FM), E = R % (FN + FM);
+        if constexpr (E < FN) lds_rd<WS * W_BYTES>(wadr[E][S2], f.w[E][S2]);
+        else lds_rd<PB * PATCH_BYTES + ((TP >> 1) * PW + (TP & 1)) * PSTRIDE + S2 * 32>(abyte[E - FN], f.a[E - FN][S2]);
     };
     auto pin_all = [&](Frags& f) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int s2 = 0; s2 < KS; ++s2) {
 #pragma unroll
-            for (int a = 0; a < FN; ++a) pin(f.w[h][a]);
+            for (int a = 0; a < FN; ++a) pin(f.w[a][s2]);
 #pragma unroll
-            for (int b = 0; b < FM; ++b) pin(f.a[h][b]);
+            for (int b = 0; b < FM; ++b) pin(f.a[b][s2]);
         }
+    };
+    auto read_all = [&](Frags& f, auto pb_, auto tp_, auto ws_) {
+        [&]<int... R>(std::integer_sequence<int, R...>) {
+            (read_one(f, pb_, tp_, ws_, std::integral_constant<int, R>{}), ...);
+        }(std::make_integer_sequence<int, NREAD>{});
     };
 
     // ---- prologue: patch 0, weight stages 0..2, the first two pieces of patch 1
     constexpr bool no_mfma = ABL & 1, no_read = ABL & 2, no_dma = ABL & 4;
+    constexpr int NR = FN + FM;                  // fragment reads of one k-step
     if (!no_dma) {
         stage_patch(0, 0, PPASS);
         stage_w(0);
         if (nsteps > 1) stage_w(1);
         if (nsteps > 2) stage_w(2);
-        if (nss > 1) stage_patch(1, 0, 2);
     }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    Frags fA, fB;
+    Frags fr;                                    // ONE fragment set: k-step s of step i+1 is read into the registers of
+                                                 // k-step s of step i right after that k-step's MFMAs have been issued
 #pragma unroll
-    for (int r = 0; r < NREAD; ++r) read_one(fA, 0, r);
-    PFA_WAIT_LGKM(0);
-    pin_all(fA);
+    for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) fr.w[a][s2] = bf16x8{};
+#pragma unroll
+        for (int b = 0; b < FM; ++b) fr.a[b][s2] = bf16x8{};
+    }
+    read_all(fr, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     stamp(1);
 
-    // one tap step; LAST: no step follows (nothing to read ahead)
-    auto body = [&](int i, Frags& cur, Frags& nxt, auto last_tag) {
-        constexpr bool LAST = decltype(last_tag)::value;
+    // one tap step, V = step index mod 8 (compile time): tap V & 3, patch buffer (V >> 2) & 1, weight slot V & 3;
+    // more: a step follows (its fragments are read ahead here).  LDS reads return in order: when k-step s starts, the reads
+    // issued after its own fragments are the 3 * NR of the following three k-steps (counted lgkmcnt; fewer in the last step).
+    auto body = [&](int i, auto v_, const bool more) {
+        constexpr int V = decltype(v_)::value;
+        constexpr int NV = (V + 1) & 7;                       // the next step's combination
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // DMA of this step
-        bool w_issued = false, p_issued = false;
-        if (!no_dma) {
-            if (i + 3 < nsteps) { stage_w(i + 3); w_issued = true; }
-            const int rel = i & 3, S = i >> 2;
-            if (rel == 3) { if (S + 2 < nss) { stage_patch(S + 2, 0, 2); p_issued = true; } }
-            else if (rel == 0) { if (S + 1 < nss) { stage_patch(S + 1, 2, 4); p_issued = true; } }
-            else if (rel == 1) { if (S + 1 < nss) { stage_patch(S + 1, 4, 6); p_issued = true; } }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // MFMAs of step i with the reads of step i+1 between them
-        int rnext = 0;
+        // DMA of this step: up to WP weight pieces (stage i+3) and three pieces of the next super-step's patch
+        const bool w_issued = !no_dma && i + 3 < nsteps;
+        constexpr int rel = V & 3;
+        const int pS = (i >> 2) + 1;
+        constexpr int pj = rel == 0 ? 0 : 3;
+        const bool p_issued = !no_dma && rel < 2 && pS < nss;
+        auto dma_op = [&](int k) {               // op k of this step's list: W pieces first, then the three patch pieces
+            if (k < WP) { if (w_issued) stage_w_piece(i + 3, k); }
+            else if (p_issued) stage_patch(pS, pj + (k - WP), pj + (k - WP) + 1);
+        };
+        constexpr int NOPS = WP + 3;
+        auto kstep = [&](auto s2_) {
+            constexpr int S2 = decltype(s2_)::value;
+            // fragments of k-step S2 have landed
+            if (!no_read) {
+                if (more) PFA_WAIT_LGKM((KS - 1) * NR); else PFA_WAIT_LGKM((KS - 1 - S2) * NR);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+                for (int a = 0; a < FN; ++a) pin(fr.w[a][S2]);
 #pragma unroll
-            for (int a = 0; a < FN; ++a)
+                for (int b = 0; b < FM; ++b) pin(fr.a[b][S2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!no_mfma) {
 #pragma unroll
-                for (int b = 0; b < FM; ++b) {
-                    if (!no_mfma) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.w[h][a], cur.a[h][b], acc[a][b], 0, 0, 0);
-                    const int m = (h * FN + a) * FM + b;                 // MFMA index 0 .. NMFMA-1
-                    const int want = ((m + 1) * NREAD) / NMFMA;          // reads that should have been issued after it
-                    if (want > rnext) {
-                        if (!LAST && !no_read) {
-                            __builtin_amdgcn_sched_barrier(0);
+                for (int a = 0; a < FN; ++a)
 #pragma unroll
-                            for (int r = rnext; r < want; ++r) read_one(nxt, i + 1, r);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        rnext = want;
-                    }
-                }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!LAST && !no_read) {
-            PFA_WAIT_LGKM(0);
-            pin_all(nxt);
-        }
-        if (w_issued && p_issued) wait_vm<WP + 2>();
+                    for (int b = 0; b < FM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.w[a][S2], fr.a[b][S2], acc[a][b], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the same k-step of the next tap step, into the registers just consumed
+            if (!no_read && more) {
+                [&]<int... R>(std::integer_sequence<int, R...>) {
+                    (read_one(fr, std::integral_constant<int, (NV >> 2) & 1>{}, std::integral_constant<int, NV & 3>{},
+                              std::integral_constant<int, NV & 3>{}, std::integral_constant<int, S2 * NR + R>{}), ...);
+                }(std::make_integer_sequence<int, NR>{});
+            }
+            // this step's DMA ops, spread over the k-steps
+#pragma unroll
+            for (int k = 0; k < NOPS; ++k)
+                if (S2 == (k * KS) / NOPS) dma_op(k);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{});
+        static_assert(KS == 4, "k-steps of a tap step");
+        if (w_issued && p_issued) wait_vm<WP + 3>();
         else if (w_issued) wait_vm<WP>();
-        else if (p_issued) wait_vm<2>();
+        else if (p_issued) wait_vm<3>();
         else wait_vm<0>();
     };
-    std::false_type more;
-    std::true_type last;
-    int i = 0;                                   // nsteps is a multiple of 4
-    for (; i + 2 < nsteps; i += 2) {
-        body(i, fA, fB, more);
-        body(i + 1, fB, fA, more);
+    // Each step body exists ONCE (duplicated tail copies cost registers, and a spilled fragment register would be saved
+    // before its in-flight LDS read has landed): `more` is a run-time flag only in the last step of a super-step.
+#define PFA_STEP(V, MORE) body(i + V, std::integral_constant<int, V>{}, MORE)
+    for (int i = 0; i < nsteps; i += 8) {        // nsteps is a multiple of 4
+        const bool second = i + 4 < nsteps;      // this group has its second super-step
+        PFA_STEP(0, true); PFA_STEP(1, true); PFA_STEP(2, true); PFA_STEP(3, second);
+        if (!second) break;
+        PFA_STEP(4, true); PFA_STEP(5, true); PFA_STEP(6, true); PFA_STEP(7, i + 8 < nsteps);
     }
-    body(i, fA, fB, more);
-    body(i + 1, fB, fA, last);
+#undef PFA_STEP
     stamp(2);
 
-    // ---- epilogue: through LDS, whole NHWC rows out (patch_epilogue.h)
-    int prow[FM];
+    // ---- epilogue: accumulators -> fp32 [position][channel] image in LDS -> whole NHWC rows out (patch_epilogue.h).
+    // 32x32 accumulator: lane holds, for register group g = 0..3, channels 8 g + 4 lh .. +3 of position lr of the tile.
+    constexpr int RS = patch_image_stride<BN>();
+    __syncthreads();                             // every wave is done with the staging buffers
 #pragma unroll
-    for (int b = 0; b < FM; ++b) prow[b] = frow[b] * TX + fcol[b];
+    for (int b = 0; b < FM; ++b) {
+        char* row = smem + tpos[b] * RS;
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(row + (wn * (BN / 2) + a * 32 + 8 * g + 4 * lh) * 4) = v;
+            }
+    }
+    __syncthreads();
     auto pix_of = [&](int r, bool& valid, size_t& opix) {
         const int qy = qy0 + r / TX, qx = qx0 + r % TX;
         valid = qy < p.hq && qx < p.wq;
@@ -287,7 +345,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         else opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
     };
     const size_t trow = (((size_t)img * q.tiles_y + ty) * q.tiles_x + tx) * (MODE == 0 ? 4 : 1) + cls;
-    patch_epilogue<BN>(p, acc, prow, n0, wn, tid, split, trow, smem, pix_of);
+    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of);
     if (q.stamps) {
         __builtin_amdgcn_s_waitcnt(0);  // (stamps only: the stores have been issued AND accepted)
         stamp(3);

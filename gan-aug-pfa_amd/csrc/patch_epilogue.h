@@ -28,28 +28,21 @@ __device__ __forceinline__ void load8f(const float* p, bool vec, int limit, floa
     }
 }
 
+// LDS row stride of the fp32 [position][channel] image a kernel writes before calling patch_epilogue_rows
+template <int BN> constexpr int patch_image_stride() { return BN * 4 + 16; }
+
 // pix_of(r, valid, opix): tile-local position r (0..255, the LDS row) -> does it exist, its output pixel index.
-// acc[a][b]: lane holds channels wn*(BN/2) + a*16 + 4*kk .. +3 of tile position prow[b] + lrow.
+// The caller has written its accumulators to smem as float32 [256 positions][BN channels] with row stride
+// patch_image_stride<BN>() and passed a barrier.
 template <int BN, typename PixOf>
-__device__ __forceinline__ void patch_epilogue(const GatherK& p, f32x4 (&acc)[BN / 32][4], const int (&prow)[4],
-                                               const int n0, const int wn, const int tid, const int split,
-                                               const size_t trow, char* smem, PixOf pix_of) {
-    constexpr int FN = BN / 32;
-    constexpr int RS = BN * 4 + 16;              // LDS row stride of the fp32 image
+__device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int n0, const int tid, const int split,
+                                                    const size_t trow, char* smem, PixOf pix_of) {
+    constexpr int RS = patch_image_stride<BN>();
     constexpr int CPR = BN / 8;                  // 16-byte output chunks per row
     constexpr int RPP = 512 / CPR;               // rows per pass
     constexpr int NP = 256 / RPP;                // passes: 8 (BN 128) or 4 (BN 64)
     typedef bf16_t T;
-    const int lane = tid & 63, lrow = lane & 15, kk = lane >> 4;
-
-    __syncthreads();                             // every wave is done with the staging buffers
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        char* row = smem + (prow[b] + lrow) * RS;
-#pragma unroll
-        for (int a = 0; a < FN; ++a) *(f32x4*)(row + (wn * (BN / 2) + a * 16 + 4 * kk) * 4) = acc[a][b];
-    }
-    __syncthreads();
+    const int lane = tid & 63;
 
     const int cc = tid % CPR, rsub = tid / CPR;
     const int col = n0 + cc * 8;                 // first of this thread's 8 output columns
@@ -94,71 +87,78 @@ __device__ __forceinline__ void patch_epilogue(const GatherK& p, f32x4 (&acc)[BN
         load8f(p.fuse_shift + col, vec, p.n - col, sh);
     }
 
-    // ---- the rows: operand loads of the fused backward first (all in flight together), then arithmetic and stores
-    bool valid[NP];
-    size_t opix[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        pix_of(rsub + k * RPP, valid[k], opix[k]);
-        valid[k] = valid[k] && live;
-    }
-    bf16x8 xr[NP], gr[NP];
+    // ---- the rows, four at a time: operand loads of the fused backward first (in flight together), then arithmetic and
+    //      stores.  (Activations here are LeakyReLU / ReLU / none: the route excludes tanh.)
+    auto act_of = [&](float t, int act) { return act == PFA_ACT_LRELU ? (t >= 0.f ? t : t * p.slope) : act == PFA_ACT_RELU ? (t > 0.f ? t : 0.f) : t; };
     const bool has_g2 = fused && p.fuse_g2 != nullptr;
-    if (fused) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const size_t e = valid[k] ? opix[k] * old + ocol : 0;         // (rows without work read element 0: no branch per load)
-            xr[k] = *(const bf16x8*)(p.fuse_raw + e * sizeof(T));
-        }
-        if (has_g2) {
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const size_t e = valid[k] ? opix[k] * old + ocol : 0;
-                gr[k] = *(const bf16x8*)(p.fuse_g2 + e * sizeof(T));
-            }
-        }
-    }
     float ss[8], sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ss[e] = 0.f; sq[e] = 0.f; }
     const bool stats = p.psum != nullptr;
+    constexpr int RB = 4;                        // rows per batch
+    static_assert(NP % RB == 0, "row batches");
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        if (!valid[k]) continue;
-        const f32x4 lo = *(const f32x4*)(lrd + k * RPP * RS), hi = *(const f32x4*)(lrd + k * RPP * RS + 16);
-        float v[8];
+    for (int k0 = 0; k0 < NP; k0 += RB) {
+        bool valid[RB];
+        size_t opix[RB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
-        bf16x8 o, o2;
+        for (int k = 0; k < RB; ++k) {
+            pix_of(rsub + (k0 + k) * RPP, valid[k], opix[k]);
+            valid[k] = valid[k] && live;
+        }
+        bf16x8 xr[RB], gr[RB];
         if (fused) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = (float)xr[k][e];
-                const float y = x * sc[e] + sh[e];
-                float d = act_grad(y, p.fuse_act1, p.slope) * v[e];
-                if (has_g2) d += act_grad(y, p.fuse_act2, p.slope) * (float)gr[k][e];
-                ss[e] += d;
-                sq[e] += d * ((x - mu[e]) * is[e]);
-                o[e] = (bf16_t)d;
+            for (int k = 0; k < RB; ++k) {
+                const size_t e = valid[k] ? opix[k] * old + ocol : 0;     // (rows without work read element 0: no branch per load)
+                xr[k] = *(const bf16x8*)(p.fuse_raw + e * sizeof(T));
             }
-        } else if (p.fuse_out == 3) {
+            if (has_g2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float y = v[e] * sc[e] + sh[e];
-                o[e] = (bf16_t)apply_act(y, p.act, p.slope);
-                o2[e] = (bf16_t)apply_act(y, p.fuse_act2, p.slope);
-            }
-            if (p.out2 && col < p.ld2) *(bf16x8*)(p.out2 + (opix[k] * p.ld2 + col) * sizeof(T)) = o2;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                ss[e] += v[e];
-                sq[e] += v[e] * v[e];
-                const float t = v[e];
-                o[e] = (bf16_t)(p.act == PFA_ACT_LRELU ? (t >= 0.f ? t : t * p.slope) : p.act == PFA_ACT_RELU ? (t > 0.f ? t : 0.f) : t);
+                for (int k = 0; k < RB; ++k) {
+                    const size_t e = valid[k] ? opix[k] * old + ocol : 0;
+                    gr[k] = *(const bf16x8*)(p.fuse_g2 + e * sizeof(T));
+                }
             }
         }
-        *(bf16x8*)(obase + (opix[k] * old + ocol) * sizeof(T)) = o;
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            if (!valid[k]) continue;
+            const char* src = lrd + (k0 + k) * RPP * RS;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
+            bf16x8 o, o2;
+            if (fused) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (float)xr[k][e];
+                    const float y = x * sc[e] + sh[e];
+                    float d = act_grad(y, p.fuse_act1, p.slope) * v[e];
+                    if (has_g2) d += act_grad(y, p.fuse_act2, p.slope) * (float)gr[k][e];
+                    ss[e] += d;
+                    sq[e] += d * ((x - mu[e]) * is[e]);
+                    o[e] = (bf16_t)d;
+                }
+            } else if (p.fuse_out == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float y = v[e] * sc[e] + sh[e];
+                    o[e] = (bf16_t)act_of(y, p.act);
+                    o2[e] = (bf16_t)act_of(y, p.fuse_act2);
+                }
+                if (p.out2 && col < p.ld2) *(bf16x8*)(p.out2 + (opix[k] * p.ld2 + col) * sizeof(T)) = o2;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    ss[e] += v[e];
+                    sq[e] += v[e] * v[e];
+                    o[e] = (bf16_t)act_of(v[e], p.act);
+                }
+            }
+            *(bf16x8*)(obase + (opix[k] * old + ocol) * sizeof(T)) = o;
+        }
     }
 
     // ---- partial statistics of this tile: lanes that share a chunk column inside a wave (lane % CPR), then the 8 waves

@@ -25,9 +25,10 @@ L = [
  ("e4 dgrad",  K.TCONV_S2, (16, 16, [512]), 256, (16, 16), 1),
 ]
 lib = _lib.lib()
-arms = [("ring", 1), ("patch2", 0)]
-if os.environ.get("PFA_ARMS"):
-    arms = [(a.split("=")[0], int(a.split("=")[1])) for a in os.environ["PFA_ARMS"].split(",")]
+arms = [("ring", {3: 1}), ("patch2", {3: 0})]
+if os.environ.get("PFA_ARMS"):          # e.g. PFA_ARMS="dp0=7:0,dp1=7:11,dp2=7:12"
+    arms = [(a.split("=")[0], {int(kv.split(":")[0]): int(kv.split(":")[1]) for kv in a.split("=")[1].split(";")})
+            for a in os.environ["PFA_ARMS"].split(",")]
 rows = []
 for name, mode, (h, w, cs), n, (hq, wq), per_step in L:
     srcs = [T(B, h, w, c) for c in cs]
@@ -40,8 +41,9 @@ for name, mode, (h, w, cs), n, (hq, wq), per_step in L:
     times = {a: [] for a, _ in arms}
     kern = {}
     for rnd in range(7):
-        for arm, knob in arms:
-            lib.pfa_set_knob(3, knob)
+        for arm, knobs in arms:
+            for kid in (3, 7):
+                lib.pfa_set_knob(kid, knobs.get(kid, 0))
             for _ in range(2 if rnd == 0 else 0):
                 K.gather_gemm(mode, srcs, wgt, n, [o], (B, hq, wq), ws)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,6 +55,7 @@ for name, mode, (h, w, cs), n, (hq, wq), per_step in L:
             times[arm].append(e0.elapsed_time(e1) * 1e3 / reps)
             kern[arm] = lib.pfa_last_gather_kernel().decode()
     lib.pfa_set_knob(3, 0)
+    lib.pfa_set_knob(7, 0)
     row = [name]
     for arm, _ in arms:
         med, mn = statistics.median(times[arm]), min(times[arm])
