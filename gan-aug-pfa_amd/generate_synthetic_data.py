@@ -49,11 +49,33 @@ def generate_data(args):
     gen.load_state_dict(torch.load(args.checkpoint, map_location=device))      # strict, like the reference
     gen.eval()
     count = 0
-    for i, batch in enumerate(loader):
-        if batch is None:
-            continue
-        a = batch["image1"].to(device)
-        fake_u8 = gen.generate_uint8(a).cpu().numpy()       # [B,H,W,3] bytes: de-normalised and converted on the device
+
+    def batches():
+        for i, batch in enumerate(loader):
+            if batch is not None:
+                yield i, batch
+
+    def results():
+        """(loader index, batch dict, fake uint8 [B,H,W,3]): on a GPU generator the fixed-shape batches go through the
+        captured-graph pipeline (pfa_gan.TilePipeline: pinned double buffering, no blocking .cpu() per batch) and the ragged
+        last one through the eager path; elsewhere the plain forward."""
+        if device.type == "cuda" and gen.fused():
+            tiles = pfa_gan.TilePipeline(gen, args.batch_size, args.size)
+            held = []
+
+            def feed():
+                for i, batch in batches():
+                    held.append((i, batch))
+                    yield batch["image1"]
+            for _, u8 in tiles(feed()):
+                i, batch = held.pop(0)
+                yield i, batch, u8
+        else:
+            for i, batch in batches():
+                yield i, batch, gen.generate_uint8(batch["image1"].to(device)).cpu().numpy()
+
+    for i, batch, fake_u8 in results():
+        a = batch["image1"]
         for j in range(a.size(0)):
             idx = i * args.batch_size + j
             city = batch["city"][j]

@@ -2,3 +2,4 @@
 from .models import NLayerDiscriminator, UNetGenerator, UnetSkipConnectionBlock  # noqa: F401
 from .trainer import (FusedAdam, GanTrainer, allreduce_mean_grads, broadcast_model, load_training_state,  # noqa: F401
                       train_gan_one_epoch)
+from .inference import TilePipeline  # noqa: F401

@@ -231,3 +231,73 @@ def discriminator_bwd(st, cache, dout, need_dx=False):
         if i == 0:
             dx = dxi
     return grads, dx
+
+
+# ----------------------------------------------------------------------- bf16 storage emulation
+# The throughput mode of the HIP engines keeps every tensor that lives in HBM in bfloat16 and everything inside a kernel
+# in float32: conv accumulators, the BatchNorm statistics (taken from the float32 accumulators), the normalisation
+# arithmetic.  These two functions restate the forward with a round-to-nearest-even bf16 at exactly those storage
+# points (gan-aug-pfa_amd/pfa_gan/engine.py: `raw`, `aL`/`aR`, `uR`, `fake`; the bf16 weight shadows), so that a bf16
+# network-level parity test can be as tight as the per-kernel ones: what remains is the order of the float32 sums and
+# the occasional rounding tie that falls the other way.
+def _bf16(x):
+    from .fill import bf16_round
+    return bf16_round(np.asarray(x, F32))
+
+
+def _bn_coeffs_train(acc, gamma, beta):
+    a64 = acc.astype(np.float64)
+    mean = a64.mean(axis=(0, 2, 3))
+    var = a64.var(axis=(0, 2, 3))
+    scale = (gamma.astype(np.float64) / np.sqrt(var + ops.BN_EPS)).astype(F32)
+    shift = (beta.astype(np.float64) - mean * scale.astype(np.float64)).astype(F32)
+    return scale, shift
+
+
+def _affine(raw, scale, shift):
+    return (raw.astype(F32) * scale[None, :, None, None] + shift[None, :, None, None]).astype(F32)
+
+
+def generator_fwd_bf16(st, x, num_downs=7):
+    """Train-mode UNetGenerator forward with the engine's bf16 storage points (see above).  Returns the tanh output."""
+    lv = g_levels(num_downs)
+    w = lambda k: _bf16(st[k])
+    a_l = _bf16(x)                                   # operand of the next down-conv
+    relu_skip = []                                   # ReLU view of every encoder activation (decoder operand)
+    for k in range(num_downs):
+        acc = ops.conv2d_fwd(a_l, w(lv[k]["down"] + ".weight"), None, 2)
+        if k == num_downs - 1:                       # innermost: consumed through ReLU only
+            relu_skip.append(_bf16(ops.relu(acc)))
+            break
+        if lv[k]["down_bn"]:
+            scale, shift = _bn_coeffs_train(acc, st[lv[k]["down_bn"] + ".weight"], st[lv[k]["down_bn"] + ".bias"])
+            y = _affine(_bf16(acc), scale, shift)    # the raw conv output is stored (bf16), then normalised
+        else:
+            y = acc                                  # outermost level: both views straight from the accumulators
+        relu_skip.append(_bf16(ops.relu(y)))
+        a_l = _bf16(ops.leaky_relu(y))
+    u = None
+    for k in range(num_downs - 1, 0, -1):
+        src = relu_skip[k] if u is None else np.concatenate([relu_skip[k], u], axis=1)
+        acc = ops.convT2d_fwd(src, w(lv[k]["up"] + ".weight"), None)
+        scale, shift = _bn_coeffs_train(acc, st[lv[k]["up_bn"] + ".weight"], st[lv[k]["up_bn"] + ".bias"])
+        u = _bf16(ops.relu(_affine(_bf16(acc), scale, shift)))
+    src = np.concatenate([relu_skip[0], u], axis=1)
+    acc = ops.convT2d_fwd(src, w(lv[0]["up"] + ".weight"), st[lv[0]["up"] + ".bias"])
+    return _bf16(np.tanh(acc).astype(F32))
+
+
+def discriminator_fwd_bf16(st, x, n_layers=3):
+    """Train-mode NLayerDiscriminator forward with the engine's bf16 storage points.  Returns the logits."""
+    layers = d_layers(n_layers)
+    h = _bf16(x)
+    for i, (ck, bk, s, has_b) in enumerate(layers):
+        acc = ops.conv2d_fwd(h, _bf16(st[ck + ".weight"]), st[ck + ".bias"] if has_b else None, s)
+        if bk:
+            scale, shift = _bn_coeffs_train(acc, st[bk + ".weight"], st[bk + ".bias"])
+            h = _bf16(ops.leaky_relu(_affine(_bf16(acc), scale, shift)))
+        elif i < len(layers) - 1:
+            h = _bf16(ops.leaky_relu(acc))
+        else:
+            h = _bf16(acc)
+    return h

@@ -85,6 +85,37 @@ def test_discriminator_fp32_vs_reference(golden, case):
     assert_close(ye.cpu().numpy(), z[f"{name}.d.y_eval"], ABS, REL, "D eval forward")
 
 
+@pytest.mark.parametrize("case", NET_CASES, ids=[c[0] for c in NET_CASES])
+def test_bf16_networks_match_the_bf16_storage_oracle(case):
+    """The throughput mode, gated tightly at network level: the bf16 train-mode forward of both networks against the
+    oracle restated with a bf16 rounding at the engine's storage points (oracle/nets.py: generator_fwd_bf16 /
+    discriminator_fwd_bf16).  What is left is the order of the float32 sums and rounding ties: a handful of elements one
+    bf16 ulp apart (2^-8 relative), against the 4.7e-2 a bf16 evaluation drifts from the float32 reference."""
+    name, nd, ngf, ndf, n, h = case
+    gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=1)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda().set_precision("bf16")
+    load(G, gst)
+    x = fill.uniform(f"{name}.x16", (n, 3, h, h))
+    G.train()
+    with torch.no_grad():
+        y = G(torch.from_numpy(x).cuda()).cpu().numpy()
+    want = nets.generator_fwd_bf16(gst, x, nd)
+    err = np.abs(y - want)
+    assert err.max() <= 2.0 ** -6 and np.mean(err > 2.0 ** -9) < 0.02 and err.mean() < 2e-4, \
+        f"G: max {err.max():.2e}, mean {err.mean():.2e}, frac > 2^-9 {np.mean(err > 2.0 ** -9):.3%}"
+    dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=2)
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda().set_precision("bf16")
+    load(D, dst)
+    xd = fill.uniform(f"{name}.xd16", (n, 6, h, h))
+    D.train()
+    with torch.no_grad():
+        yd = D(torch.from_numpy(xd).cuda()).cpu().numpy()
+    wantd = nets.discriminator_fwd_bf16(dst, xd)
+    errd = np.abs(yd - wantd)
+    scale = max(np.abs(wantd).max(), 1.0)
+    assert errd.max() <= 2.0 ** -6 * scale and errd.mean() < 5e-4 * scale, f"D: max {errd.max():.2e}, mean {errd.mean():.2e}"
+
+
 def _digest_ok(z, name, a, atol, rtol):
     flat = np.asarray(a).reshape(-1)
     stride = int(z[name + ".stride"])
@@ -397,6 +428,32 @@ def test_generate_uint8_equals_denormalised_forward(precision):
     got = G.generate_uint8(x).cpu()
     assert got.dtype == torch.uint8 and got.shape == (2, 64, 32, 3)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_tile_pipeline_equals_eager_generation(precision):
+    """generate_synthetic_data.py:61-71 as the captured-graph, double-buffered pipeline (pfa_gan.TilePipeline): byte for
+    byte the eager generate_uint8 of every batch, in order, including a ragged last batch and slot reuse."""
+    torch.manual_seed(4)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda().set_precision(precision).eval()
+    with torch.no_grad():                     # non-trivial running statistics
+        for m in G.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    gen = torch.Generator().manual_seed(8)
+    batches = [torch.rand((4, 3, 64, 64), generator=gen) * 2 - 1 for _ in range(5)] + [torch.rand((3, 3, 64, 64), generator=gen) * 2 - 1]
+    tiles = pfa_gan.TilePipeline(G, 4, 64)
+    before = _lib.launch_count()
+    got = list(tiles(iter(batches)))
+    assert [k for k, _ in got] == list(range(6))
+    assert _lib.launch_count() - before < 60, "the fixed-shape batches must be graph replays, not eager launches"
+    for (k, u8), x in zip(got, batches):
+        want = G.generate_uint8(x.cuda()).cpu().numpy()
+        assert u8.dtype == np.uint8 and u8.shape == want.shape
+        assert np.array_equal(u8, want), f"batch {k}"
+    again = list(tiles(iter(batches[:3])))    # the pipeline is reusable
+    assert all(np.array_equal(a[1], b[1]) for a, b in zip(again, got))
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -202,3 +202,21 @@ def test_gan_step(golden, case):
                 assert np.abs(got - want).max() < 5e-4, f"{prefix}.{k}"
             else:
                 assert_close(v, want, 1e-5, 1e-3, f"{prefix} buffer {k}")
+
+
+def test_bf16_storage_oracle_tracks_the_pinned_fp32_oracle():
+    """The bf16-storage restatement (oracle/nets.py, the checker of the bf16 network gate) is the pinned fp32 oracle plus
+    roundings: it must stay within bf16's drift of it (a few 1e-2 on a train-mode generator) and be exactly
+    bf16-representable."""
+    nd, ngf, ndf, n, h = 5, 8, 8, 2, 32
+    gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=1)
+    x = fill.uniform("bf16or.x", (n, 3, h, h))
+    y16 = nets.generator_fwd_bf16(gst, x, nd)
+    y32, _, _ = nets.generator_fwd(gst, x, nd, train=True)
+    assert np.abs(y16 - y32).max() < 6e-2 and np.abs(y16 - y32).mean() < 6e-3
+    assert np.array_equal(fill.bf16_round(y16), y16)
+    dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=2)
+    xd = fill.uniform("bf16or.xd", (n, 6, h, h))
+    d16 = nets.discriminator_fwd_bf16(dst, xd)
+    d32, _, _ = nets.discriminator_fwd(dst, xd)
+    assert np.abs(d16 - d32).max() < 3e-2 * max(1.0, np.abs(d32).max())
