@@ -55,6 +55,11 @@ bool pfa_conv_s1_patch_ok(int grad, int nb, int hin, int win, int cin, int n, in
 int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float* slab, int splitk, float* psum, float* psq,
                       int nb, int hin, int win, int cin, int n, hipStream_t st);
 
+// csrc/wgrad_patch.hip: weight gradient with the gathered patch kept in LDS (dispatched by pfa_wgrad)
+bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int* steps_out);
+size_t pfa_wgrad_patch_slab_floats(const pfa_wgrad_args* a, int slices);
+int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name);
+
 static inline int pfa_ch(int dtype) { return dtype == PFA_BF16 ? 8 : 4; }
 static inline int pfa_esize(int dtype) { return dtype == PFA_BF16 ? 2 : 4; }
 static inline int ilog2_exact(int v) {  // log2 if power of two else -1

@@ -496,9 +496,19 @@ static bool wgrad_ring(const pfa_wgrad_args* a, const WgradK& k) {
     return a->dtype == PFA_BF16 && k.dp >= 256 && k.mper >= 3 * 64 && pfa_knob(4) == 3;
 }
 
+extern "C" int pfa_wgrad_slices(const pfa_wgrad_args* a) {
+    WgradK k; int msplit; bool small_i;
+    if (int rc = wgrad_setup(a, k, msplit, small_i)) return rc < 0 ? rc : -rc;
+    int ps;
+    if (pfa_wgrad_patch_plan(a, &ps, nullptr, nullptr)) return ps;
+    return msplit * k.kgroups;
+}
+
 extern "C" size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a) {
     WgradK k; int msplit; bool small_i;
     if (wgrad_setup(a, k, msplit, small_i)) return 0;
+    int ps;
+    if (pfa_wgrad_patch_plan(a, &ps, nullptr, nullptr)) return pfa_wgrad_patch_slab_floats(a, ps);
     const int bi = small_i ? 16 : (wgrad_ring(a, k) ? 256 : 128);
     return (size_t)msplit * ((k.jtot + 127) / 128) * ((k.dp + bi - 1) / bi) * bi * 128;
 }
@@ -512,7 +522,11 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     const bool timing = pfa_timing_begin(st, &te0, &te1);
     int rc;
     const char* name;
-    if (a->dtype == PFA_BF16) {
+    int pslices = 0;
+    if (pfa_wgrad_patch_plan(a, &pslices, nullptr, nullptr)) {
+        rc = pfa_wgrad_patch(a, st, &name);
+        msplit = pslices;
+    } else if (a->dtype == PFA_BF16) {
         if (!small_i && wgrad_ring(a, k)) { rc = launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st); name = "k_wgrad<bf16,256,ring>"; }
         else if (k.kgroups == 2) { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st); name = "k_wgrad<bf16,128,kg2>"; }
         else if (small_i) { rc = launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st); name = "k_wgrad<bf16,16>"; }

@@ -248,7 +248,10 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None):
     a.dir1, a.dir2 = ptr(direct[0]), ptr(direct[1]) if len(direct) > 1 else None
     a.gat1, a.gat2 = ptr(gathered[0]), ptr(gathered[1]) if len(gathered) > 1 else None
     a.dw = ptr(dw)
-    if ws is not None and (msplit >= 8 or ws is FORCE_SLAB):
+    slices = lib().pfa_wgrad_slices(ctypes.byref(a))       # (the library may route the call to a kernel with its own slicing)
+    if slices < 0:
+        check(slices, "pfa_wgrad_slices")
+    if ws is not None and (slices >= 8 or ws is FORCE_SLAB):
         # many reduction slices over a small dw: per-slice slabs + an ordered reduce beat ~1.3 TB/s float atomics
         # (and are reproducible); with a few slices over a large dw the atomics are as fast and need no workspace
         a.slab = ptr((ws if ws is not FORCE_SLAB else _FORCE_WS).get("wgslab", lib().pfa_wgrad_slab_floats(ctypes.byref(a))))

@@ -57,7 +57,8 @@ uint64_t pfa_launch_count(void);
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
- * 5 = no K-group pairs, 6 = pairs from four slices on);
+ * 5 = no K-group pairs, 6 = pairs from four slices on, 7 = never the patch kernel of wgrad_patch.hip, 8 = the patch kernel
+ * whenever the geometry fits);
  * id 3: the input-patch kernels (conv_patch.hip: stride-1 convolutions, forward and input gradient; conv_patch2.hip: stride-2
  * convolutions and transposed convolutions): 0 = launches large enough to fill the chip, 1 = never, 2 = whenever the geometry
  * fits, 3 = the stride-1 kernel only;
@@ -172,6 +173,9 @@ typedef struct pfa_wgrad_args {
                                  /* combined in a fixed order (bitwise reproducible) instead of float atomics   */
 } pfa_wgrad_args;
 size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a);
+/* Reduction slices the call will really use (the library may take another kernel, with its own slice count, than the one
+ * a->msplit was chosen for): callers pass a slab when many slices would otherwise meet in float atomics. */
+int pfa_wgrad_slices(const pfa_wgrad_args* a);
 int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s);
 
 /* ------------------------------------------------------------------ transposed conv onto <= 8 channels

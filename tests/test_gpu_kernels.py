@@ -638,6 +638,68 @@ def test_convT_wgrad(case, dtype, ws):
         close(got, want, torch.float32, name)
 
 
+WGP_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels, stride, slab
+    ("conv_s2_32", "conv", 2, [64], 64, 64, 128, 2, False),          # e2-like: dy 32x32, 2x32 tiles, atomics
+    ("conv_s2_ragged", "conv", 1, [64], 40, 72, 128, 2, True),       # dy 20x36: ragged tile rows and columns, slab
+    ("conv_s2_16", "conv", 3, [128], 32, 32, 256, 2, False),         # dy 16x16: 4x16 tiles, two c tiles, two i tiles
+    ("conv_s1", "conv", 2, [64], 32, 32, 128, 1, False),             # c4-like: dy 31x31 (ragged 2x32 tiles)
+    ("conv_s1_16", "conv", 2, [64], 18, 17, 128, 1, True),           # dy 17x16: 4x16 tiles, ragged rows
+    ("convT_cat", "convT", 2, [128, 128], 16, 16, 64, 2, False),     # decoder: direct = concat input, gathered = dy 32x32
+    ("convT_wide", "convT", 1, [128], 16, 48, 64, 2, True),          # two tile columns of 4x16 ... (48 wide: 2x32 tiles)
+]
+
+
+@pytest.mark.parametrize("case", WGP_CASES, ids=[c[0] for c in WGP_CASES])
+def test_wgrad_patch_kernel(case, ws):
+    """Weight gradients on the patch kernel of wgrad_patch.hip (pfa_set_knob(4, 8) routes launches this small there): the
+    oracle and the older kernel (knob 4 = 7) - both strides, both tile shapes, ragged maps, the decoder's virtual concat on
+    the direct side, float atomics and the slab + ordered reduce."""
+    name, kind, n, cins, h, w, co, stride, slab = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".pw.x", (n, ci, h, w)), dtype)
+    if kind == "conv":
+        ho, wo = (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+        dy = rnd(fill.uniform(name + ".pw.dy", (n, co, ho, wo)), dtype)
+        _, want, _ = ops.conv2d_bwd(x, fill.uniform(name + ".pw.w", (co, ci, 4, 4)), dy, stride, need_dx=False)
+        rows, cols = co, ci
+    else:
+        dy = rnd(fill.uniform(name + ".pw.dy", (n, co, 2 * h, 2 * w)), dtype)
+        _, want, _ = ops.convT2d_bwd(x, fill.uniform(name + ".pw.w", (ci, co, 4, 4)), dy, need_dx=False)
+        rows, cols = ci, co
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    dyt = to_nhwc(dy, dtype)
+    lib = _lib.lib()
+    res = []
+    for knob in (8, 7):
+        dw = torch.full((rows, 16, cols), 0.5, dtype=torch.float32, device="cuda")       # the result is ADDED to dw
+        lib.pfa_set_knob(4, knob)
+        lib.pfa_gather_timing(1)
+        try:
+            before = _lib.launch_count()
+            if kind == "conv":
+                K.wgrad([dyt], srcs, dw, stride, [co], cins, ws=K.FORCE_SLAB if slab else None)
+            else:
+                K.wgrad(srcs, [dyt], dw, 2, cins, [co], ws=K.FORCE_SLAB if slab else None)
+            launches = _lib.launch_count() - before
+            torch.cuda.synchronize()
+            import ctypes
+            ms, nm, fl, by, sk = ctypes.c_float(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(lib.pfa_gather_timing_get(0, ctypes.byref(ms), ctypes.byref(nm), ctypes.byref(fl), ctypes.byref(by),
+                                                 ctypes.byref(sk)), "pfa_gather_timing_get")
+        finally:
+            lib.pfa_gather_timing(0)
+            lib.pfa_set_knob(4, 0)
+        assert nm.value.decode().startswith("k_wgrad_patch") == (knob == 8), nm.value
+        assert launches == (2 if slab else 1)
+        res.append((dw.cpu().numpy() - 0.5).reshape(rows, 4, 4, cols).transpose(0, 3, 1, 2))
+    close(res[0], want, torch.float32, name)
+    close(res[0], res[1], torch.float32, name + " vs wgrad.hip", scale=np.abs(want).max())
+
+
 @pytest.mark.parametrize("case", [("conv_co320", "conv", 2, [32], 32, 32, 320, 2), ("convT_ci256_cat", "convT", 2, [128, 128], 16, 16, 24, 2),
                                   ("conv_s1_co256", "conv", 2, [16], 23, 23, 256, 1)], ids=lambda c: c[0])
 def test_wgrad_ring_tile(case, ws):
