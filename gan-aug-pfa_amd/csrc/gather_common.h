@@ -52,6 +52,10 @@ struct Patch2Plan {
 bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan);
 int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, const char** kernel_name);
 
+// csrc/conv_image.hip: stride-2 convolution of the image-side layers (8-channel sources, 64 outputs)
+bool pfa_conv_image_ok(const GatherK& k, int dtype, int* stat_tiles);
+int pfa_conv_image(const GatherK& k, hipStream_t st, const char** kernel_name);
+
 namespace {
 
 template <typename T> struct Mma;

@@ -982,6 +982,8 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     if (int rc = fill_params(a, k, classes)) return rc;
     int ptiles = 0;
     if (k.splitk == 1 && patch_route(a, k, &ptiles)) return ptiles;
+    int itiles = 0;
+    if (k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles)) return itiles;
     Patch2Plan plan2;
     if (pfa_conv_patch2_plan(k, a->dtype, &plan2)) {
         if (plan2.splitk == 1) return plan2.stat_tiles;
@@ -1176,8 +1178,10 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     hipStream_t st = (hipStream_t)s;
     int ptiles = 0;
     const bool patch = patch_route(a, k, &ptiles);
+    int itiles = 0;
+    const bool image = !patch && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles);
     Patch2Plan plan2;
-    const bool patch2 = !patch && pfa_conv_patch2_plan(k, a->dtype, &plan2);
+    const bool patch2 = !patch && !image && pfa_conv_patch2_plan(k, a->dtype, &plan2);
     if (patch2) k.splitk = plan2.splitk;          // never more slices than the caller sized the slab for
     const TileCfg cfg = choose_cfg(k);
     int rc;
@@ -1189,6 +1193,10 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
                                a->nb, a->hs, a->ws, a->c1, a->n, st);
         g_last_gather_name = "k_conv_s1_patch<bf16,8x32,128>";
+    } else if (image) {
+        const char* nm = "";
+        rc = pfa_conv_image(kk, st, &nm);
+        g_last_gather_name = nm;
     } else if (patch2) {
         const char* nm = "";
         rc = pfa_conv_patch2(kk, plan2, st, &nm);
@@ -1229,7 +1237,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         if (rc) return rc;
         a->ntiles_stat = tiles;
     } else {
-        a->ntiles_stat = patch ? ptiles : patch2 ? plan2.stat_tiles : classes * ((k.M + cfg.bm - 1) / cfg.bm);
+        a->ntiles_stat = patch ? ptiles : image ? itiles : patch2 ? plan2.stat_tiles : classes * ((k.M + cfg.bm - 1) / cfg.bm);
     }
     return 0;
 }

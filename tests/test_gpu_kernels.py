@@ -182,6 +182,54 @@ def test_conv_s1_patch_kernel_input_gradient(case, ws):
     close(from_nhwc(outs[0], ci), from_nhwc(outs[1], ci), dtype, name + " vs implicit GEMM", scale=np.abs(want).max())
 
 
+IMAGE_CASES = [  # name, N, real channels per source, H, W, bias + LeakyReLU, two outputs through the identity affine map
+    ("e1_like", 2, [3], 64, 64, False, True),            # generator's first conv: 3 -> 64, LeakyReLU and ReLU views
+    ("e1_ragged", 1, [3], 36, 80, False, True),          # output 18 x 40: ragged tile rows and columns
+    ("c1_like", 2, [3, 3], 32, 64, True, False),         # discriminator's first conv: (A | B) -> 64, bias, LeakyReLU
+    ("c1_ragged", 3, [3, 3], 20, 36, True, False),
+]
+
+
+@pytest.mark.parametrize("case", IMAGE_CASES, ids=[c[0] for c in IMAGE_CASES])
+def test_conv_image_kernel(case, ws):
+    """The image-side stride-2 convolutions (models.py:183, :223) on conv_image.hip: the oracle, and the implicit GEMM's
+    result (pfa_set_knob(3, 1)) up to the order of the float32 sums."""
+    name, n, cins, h, w, biased, dual = case
+    dtype = torch.bfloat16
+    ci, co = sum(cins), 64
+    x = rnd(fill.uniform(name + ".ix", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".iw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    b = fill.uniform(name + ".ib", (co,), -0.5, 0.5) if biased else None
+    raw = ops.conv2d_fwd(x, wt, b, 2)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    wsh, _ = shadows(wt, dtype, cparts=[(c, K.pad_ch(c, dtype)) for c in cins], want=("same",))
+    ho, wo = raw.shape[2:]
+    lib = _lib.lib()
+    res = []
+    for knob in (0, 1):
+        outs = [torch.full((n, ho, wo, co), 7.0, dtype=dtype, device="cuda") for _ in range(2 if dual else 1)]
+        lib.pfa_set_knob(3, knob)
+        try:
+            if dual:
+                one, zero = torch.ones(co, device="cuda"), torch.zeros(co, device="cuda")
+                K.gather_gemm(K.CONV_S2, srcs, wsh, co, outs, (n, ho, wo), ws, act=K.ACT_LRELU, affine=(one, zero, K.ACT_RELU))
+            else:
+                K.gather_gemm(K.CONV_S2, srcs, wsh, co, outs, (n, ho, wo), ws, bias=torch.from_numpy(b).cuda(), act=K.ACT_LRELU)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(3, 0)
+        assert kernel.startswith("k_conv_image") == (knob == 0), kernel
+        res.append([from_nhwc(t, co) for t in outs])
+    close(res[0][0], ops.leaky_relu(raw), dtype, name + " lrelu", scale=np.abs(raw).max())
+    if dual:
+        close(res[0][1], ops.relu(raw), dtype, name + " relu", scale=np.abs(raw).max())
+    for a, bb in zip(res[0], res[1]):
+        close(a, bb, dtype, name + " vs implicit GEMM", scale=np.abs(raw).max())
+
+
 PATCH2_CASES = [  # name, kind, N, cin parts, H, W (input), Co, K slices, knob 6 (workgroups wanted), kernel, output split
     ("tconv_cat", "tconv", 2, [64, 64], 9, 33, 128, 1, 1, "k_conv_patch2<tconv,128,8x32>", None),       # ragged 8x32 tiles, virtual concat
     ("tconv_16", "tconv", 2, [128], 16, 16, 64, 1, 0, "k_conv_patch2<tconv,64,16x16>", None),          # 16x16 tile, 64-channel tile
