@@ -78,6 +78,12 @@ PROTOTYPES = {
     "pfa_tconv_scatter": (c_int, [POINTER(ScatterArgs), c_void_p]),
     "pfa_wgrad_slab_floats": (c_size_t, [POINTER(WgradArgs)]),
     "pfa_wgrad_slices": (c_int, [POINTER(WgradArgs)]),
+    "pfa_logit_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "pfa_logit_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pfa_logit_dgrad_tiles": (c_int, [c_int, c_int, c_int]),
+    "pfa_logit_dgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pfa_logit_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pfa_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_eval_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -605,8 +605,11 @@ class DiscriminatorEngine(_Engine):
             shape = (B, ho, wo, L.cout_p)
             if L.bn is None:
                 out = ctx.buf(f"c{i}.a", shape, dt)
-                K.gather_gemm(mode, a, L.w_fwd, L.cout, [out], (B, ho, wo), self.ws, bias=L.b,
-                              act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE, c_real=sum(L.in_real))
+                if self._logit_layer(i, a):
+                    K.logit_fwd(a[0], L.same, L.b, out)
+                else:
+                    K.gather_gemm(mode, a, L.w_fwd, L.cout, [out], (B, ho, wo), self.ws, bias=L.b,
+                                  act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE, c_real=sum(L.in_real))
             else:
                 raw = ctx.buf(f"c{i}.raw", shape, dt)
                 st = K.gather_gemm(mode, a, L.w_fwd, L.cout, [raw], (B, ho, wo), self.ws, bias=L.b, stats=train)
@@ -616,6 +619,12 @@ class DiscriminatorEngine(_Engine):
             ctx.v["a"][i] = out
             a, h, w = [out], ho, wo
         return a[0]
+
+    def _logit_layer(self, i, inputs):
+        """Is layer i the one-channel logit convolution (models.py:243) on a shape its vector kernels are built for?"""
+        L = self.layers[i]
+        return (i == len(self.layers) - 1 and i > 0 and L.cout == 1 and L.stride == 1 and len(inputs) == 1
+                and K.logit_ok(inputs[0], L.cout_p))
 
     def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
@@ -653,12 +662,29 @@ class DiscriminatorEngine(_Engine):
                 dr = self._bn_backward(L, ctx, f"c{i}", raw, B * ho * wo, garena, g, K.ACT_LRELU,
                                        param_grads=param_grads)
             inputs = v["srcs"] if i == 0 else [v["a"][i - 1]]
+            logit = self._logit_layer(i, inputs)
             if param_grads:
-                def pg(ws, L=L, dr=dr, inputs=inputs):
+                def pg(ws, L=L, dr=dr, inputs=inputs, logit=logit):
+                    if logit:
+                        K.logit_wgrad(dr, inputs[0], L.dw(garena), L.db(garena) if L.b is not None else None)
+                        return
                     K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=ws)
                     if L.b is not None:
                         K.colsum(dr, L.db(garena), ws, c_out=L.cout)
                 self._param_grads(side, pg)
+            if logit:
+                # input gradient fused with the LeakyReLU / BatchNorm backward of the layer below
+                Lp, prev = self.layers[i - 1], v["a"][i - 1]
+                tag = f"c{i - 1}"
+                rawp = ctx.buf(tag + ".raw", prev.shape, dt) if Lp.bn is not None else prev
+                dyp = ctx.buf(tag + ".dy", prev.shape, dt)
+                f = self._fuse_spec(Lp, ctx, tag, 1, rawp, K.ACT_LRELU)
+                part, nt = K.logit_dgrad(dr, L.same, rawp, f.get("scale"), f.get("shift"), f.get("mean"), f.get("invstd"),
+                                         K.ACT_LRELU, dyp, self.ws_cur)
+                hp, wp = prev.shape[1:3]
+                ready = self._finish_fused(Lp, ctx, tag, rawp, B * hp * wp, garena, dyp, (part, None, nt),
+                                           param_grads=param_grads)
+                continue
             if i > 0 or need_dx:
                 hin, win = inputs[0].shape[1:3]
                 cp = sum(L.in_pad)

@@ -258,6 +258,36 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None):
     check(lib().pfa_wgrad(ctypes.byref(a), stream()), "pfa_wgrad")
 
 
+# ------------------------------------------------------------------------------- the PatchGAN logit layer
+def logit_ok(x, ld):
+    """Are the single-output-channel kernels built for this input [B,h,w,c]?"""
+    return bool(lib().pfa_logit_supported(dt_code(x.dtype), x.shape[3], ld, x.shape[1], x.shape[2]))
+
+
+def logit_fwd(x, w, bias, logits):
+    B, h, wd, c = x.shape
+    check(lib().pfa_logit_fwd(ptr(x), ptr(w), ptr(bias), ptr(logits), B, h, wd, c, logits.shape[3], stream()),
+          "pfa_logit_fwd")
+
+
+def logit_dgrad(dlogits, w, raw, scale, shift, mean, invstd, act, dy, ws):
+    """dy = act'(scale*raw+shift) * (dlogits (*) w); returns (part, ntiles) for bn_bwd_finalize, or (None, 0)."""
+    B, h, wd, c = raw.shape
+    part, nt = None, 0
+    if mean is not None:
+        nt = lib().pfa_logit_dgrad_tiles(B, h, wd)
+        part = ws.get("bnpart", 2 * nt * c)
+    check(lib().pfa_logit_dgrad(ptr(dlogits), dlogits.shape[3], ptr(w), ptr(raw), ptr(scale), ptr(shift), ptr(mean),
+                                ptr(invstd), act, SLOPE, ptr(dy), ptr(part), B, h, wd, c, stream()), "pfa_logit_dgrad")
+    return part, nt
+
+
+def logit_wgrad(dlogits, x, dw, db):
+    B, h, wd, c = x.shape
+    check(lib().pfa_logit_wgrad(ptr(dlogits), dlogits.shape[3], ptr(x), ptr(dw), ptr(db), B, h, wd, c, stream()),
+          "pfa_logit_wgrad")
+
+
 # ------------------------------------------------------------------------------- BatchNorm
 def bn_finalize(psum, psq, ntiles, c, count, gamma, beta, running_mean, running_var, nbt, scale, shift, mean, invstd,
                 repeats=1):

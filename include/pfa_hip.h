@@ -178,6 +178,28 @@ size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a);
 int pfa_wgrad_slices(const pfa_wgrad_args* a);
 int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s);
 
+/* ------------------------------------------------------------------ the PatchGAN logit layer
+ * Conv2d(512, 1, kernel 4, stride 1, padding 1) + bias: the discriminator's last layer (models.py:243), bf16.
+ * One output channel makes the layer bandwidth-shaped; these three vector kernels replace its launches on the MFMA
+ * kernels (pfa_gather_gemm CONV_S1 / CONV_S1_DGRAD + pfa_bn_bwd_reduce, pfa_wgrad + pfa_colsum).
+ *   x        [nb][h][w][c] activations entering the layer; logits / dlogits [nb][h-1][w-1][ld], value in channel 0
+ *   w        [16 taps][c] bf16: the layer's weights, tap = ky*4+kx (the engine's "same" shadow of the [1][c][4][4] master)
+ * pfa_logit_supported: 1 when the kernels are built for this shape (else callers keep the general kernels). */
+int pfa_logit_supported(int dtype, int c, int ld, int h, int w);
+/* logits[.., 0] = bias[0] + sum_{tap,c} x[oy-1+ky][ox-1+kx][c] * w[tap][c]; channels 1..ld-1 are written as zeros. */
+int pfa_logit_fwd(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c, int ld,
+                  pfa_stream s);
+/* g[y][x][c] = sum_tap dlogits[y+1-ky][x+1-kx] * w[tap][c], then the backward of what feeds the layer, as
+ * pfa_bn_bwd_reduce computes it: dy = act'(scale*raw + shift) * g (scale == NULL: identity map), and when mean != NULL
+ * the partial sums of dy and dy*xhat -> part[2][pfa_logit_dgrad_tiles(nb,h,wd)][c] for pfa_bn_bwd_finalize. */
+int pfa_logit_dgrad_tiles(int nb, int h, int wd);
+int pfa_logit_dgrad(const void* dlogits, int ld, const void* w, const void* raw, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, int act, float slope, void* dy, float* part, int nb, int h,
+                    int wd, int c, pfa_stream s);
+/* dw[tap][c] += sum_pixels dlogits * x[pixel + tap][c] (float atomics), db[0] += sum dlogits (db may be NULL). */
+int pfa_logit_wgrad(const void* dlogits, int ld, const void* x, float* dw, float* db, int nb, int h, int wd, int c,
+                    pfa_stream s);
+
 /* ------------------------------------------------------------------ transposed conv onto <= 8 channels
  * out[b][2*iy-1+ky][2*ix-1+kx][co] = act( bias[co] + sum_c src[b][iy][ix][c] * w[co][ky*4+kx][c] )
  * Replaces, where the output has only a few channels: the generator's outermost

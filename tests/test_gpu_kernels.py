@@ -533,6 +533,80 @@ def test_fused_backward_epilogue(case, dtype, ws):
         assert st is None
 
 
+LOGIT_CASES = [  # name, N, H, W of the 512-channel input
+    ("c5_256", 2, 31, 31),          # the layer's input at 256 x 256 tiles
+    ("c5_ragged", 1, 9, 37),        # two column tiles, the second 5 wide; odd row count
+    ("c5_wide", 1, 4, 63),          # the input width at 512 x 512 tiles
+    ("c5_tiny", 2, 2, 2),           # one logit per image
+]
+
+
+@pytest.mark.parametrize("case", LOGIT_CASES, ids=[c[0] for c in LOGIT_CASES])
+def test_logit_layer_kernels(case, ws):
+    """The discriminator's Conv2d(512, 1, 4, 1, 1) (models.py:243) on conv_logit.hip: forward, input gradient fused with
+    the LeakyReLU + BatchNorm backward of the layer below (values and partial sums), weight and bias gradient - against
+    the oracle's convolution."""
+    name, n, h, w = case
+    dtype, c = torch.bfloat16, 512
+    x = rnd(fill.uniform(name + ".lx", (n, c, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".lw", (1, c, 4, 4), -0.25, 0.25), dtype)
+    b = fill.uniform(name + ".lb", (1,), -0.5, 0.5)
+    want = ops.conv2d_fwd(x, wt, b, 1)                                   # [n, 1, h-1, w-1]
+    ho, wo = want.shape[2:]
+    same, _ = shadows(wt, dtype, want=("same",))
+    xd = to_nhwc(x, dtype)
+    assert K.logit_ok(xd, 8)
+    logits = torch.full((n, ho, wo, 8), 7.0, dtype=dtype, device="cuda")
+    before = _lib.launch_count()
+    K.logit_fwd(xd, same, torch.from_numpy(b).cuda(), logits)
+    assert _lib.launch_count() - before == 1
+    close(from_nhwc(logits, 1), want, dtype, name + ".logits")
+    assert float(logits[..., 1:].abs().max()) == 0.0                    # pad channels are written as zeros
+
+    # backward: dlogits -> (dw, db) and dy = LeakyReLU'(scale*raw + shift) * dx with the BatchNorm partial sums
+    dl = rnd(fill.uniform(name + ".ldl", (n, 1, ho, wo), -1.0, 1.0), dtype)
+    dld = to_nhwc(dl, dtype)
+    dx, dw, db = ops.conv2d_bwd(x, wt, dl, 1)
+    scale, shift = fill.uniform(name + ".lsc", (c,), 0.5, 1.5), fill.uniform(name + ".lsh", (c,), -0.3, 0.3)
+    mean, invstd = fill.uniform(name + ".lmu", (c,), -0.2, 0.2), fill.uniform(name + ".lis", (c,), 0.5, 2.0)
+    y = x * scale[None, :, None, None] + shift[None, :, None, None]
+    want_dy = np.where(y > 0, 1.0, 0.2) * dx
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for bn in (True, False):
+        dy = torch.full((n, h, w, c), 7.0, dtype=dtype, device="cuda")
+        args = (dev(scale), dev(shift), dev(mean), dev(invstd)) if bn else (None, None, None, None)
+        part, nt = K.logit_dgrad(dld, same, xd, *args, K.ACT_LRELU, dy, ws)
+        wdy = want_dy if bn else np.where(x > 0, 1.0, 0.2) * dx
+        close(from_nhwc(dy, c), wdy, dtype, name + ".dy", scale=np.abs(dx).max())
+        if bn:
+            torch.cuda.synchronize()
+            ps = part[: 2 * nt * c].view(2, nt, c).double().sum(1).cpu().numpy()
+            xhat = (x - mean[None, :, None, None]) * invstd[None, :, None, None]
+            close(ps[0], wdy.astype(np.float64).sum(axis=(0, 2, 3)), dtype, name + ".sum_dy",
+                  scale=np.abs(wdy).sum(axis=(0, 2, 3)).max())
+            close(ps[1], (wdy.astype(np.float64) * xhat).sum(axis=(0, 2, 3)), dtype, name + ".sum_dy_xhat",
+                  scale=np.abs(wdy * xhat).sum(axis=(0, 2, 3)).max())
+        else:
+            assert part is None
+    gw = torch.full((1, 16, c), 0.5, dtype=torch.float32, device="cuda")      # gradients accumulate
+    gb = torch.full((1,), 0.25, dtype=torch.float32, device="cuda")
+    K.logit_wgrad(dld, xd, gw, gb)
+    torch.cuda.synchronize()
+    got_w = (gw - 0.5).cpu().numpy().reshape(1, 4, 4, c).transpose(0, 3, 1, 2)
+    close(got_w, dw, torch.float32, name + ".dw", scale=np.abs(dw).max())
+    close((gb - 0.25).cpu().numpy(), db, torch.float32, name + ".db", scale=max(np.abs(dl).sum(), 1.0))
+
+
+def test_logit_layer_support():
+    lib = _lib.lib()
+    assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 512, 8, 31, 31) == 1
+    assert lib.pfa_logit_supported(K.dt_code(torch.float32), 512, 4, 31, 31) == 0      # float32 keeps the general kernels
+    assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 256, 8, 31, 31) == 0
+    x = torch.zeros((1, 4, 4, 256), dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_lib.PfaError):
+        K.logit_fwd(x, x, None, torch.zeros((1, 3, 3, 8), dtype=torch.bfloat16, device="cuda"))
+
+
 SCATTER_CASES = [  # name, N, cin parts, H, W, Co, bias, act
     ("d1", 2, [64, 64], 8, 8, 3, True, K.ACT_TANH),              # the generator's output layer: two 64-channel sources
     ("d1_ragged", 1, [64, 64], 7, 33, 3, True, K.ACT_TANH),      # H not a multiple of the 6-row tile, W crosses a tile

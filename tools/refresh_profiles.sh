@@ -1,17 +1,27 @@
 #!/bin/bash
-# Regenerates the rocprofv3 summaries under gpurun_out/ (copy what should be judged into profiles/): run through gpurun from
-# the repo root.  One trace of the default three-stream bench, one of the one-stream mode bench.py's roofline is measured in.
+# Round-2 profile artefacts -> gpurun_out/$TAG (copy what should be judged into profiles/): run through gpurun from the repo
+# root:  gpurun -- bash tools/refresh_profiles.sh r2final <commit>
+#   p3_* / p1_*      rocprofv3 --kernel-trace --stats of bench.py, three streams (default) / one stream (the mode of the
+#                    bench's live roofline measurement): summaries, kernel stats csv, per-launch listing
+#   traffic.json     HBM bytes per launch of every MFMA kernel family (two --pmc passes, kernel trace only)
+#   bench_line.json  the JSON line of a default `python bench.py` run of the same call (reads traffic.json's copy under
+#                    profiles/ if present)
 set -e
+TAG=${1:-prof}
+COMMIT=${2:-?}
 R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+bash $R/tools/prof_step.sh $TAG > $O/prof_step.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof_eager $R/gpurun_out/prof_one
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_eager -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_eager.json 2> $R/gpurun_out/prof_eager.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_one -- python $R/bench.py --steps 5 --warmup 2 --no-overlap --no-cpu-baseline --no-roofline > $R/gpurun_out/prof_one.json 2> $R/gpurun_out/prof_one.err
+rm -rf $O/pmc_fetch $O/pmc_write
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline > /dev/null 2> $O/pmc_write.err
 cd $R
-python tools/prof_summary.py gpurun_out/prof_eager 7 > gpurun_out/prof_eager_summary.txt
-python tools/prof_summary.py gpurun_out/prof_one 7 > gpurun_out/prof_one_summary.txt
-cp gpurun_out/prof_eager/*/*_kernel_stats.csv gpurun_out/prof_eager_kernel_stats.csv
-cp gpurun_out/prof_one/*/*_kernel_stats.csv gpurun_out/prof_one_kernel_stats.csv
-rm -rf gpurun_out/prof_eager gpurun_out/prof_one          # the raw traces exceed what gpurun merges back
-python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-cat gpurun_out/bench_final.json
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json train_b16_256_bf16 $COMMIT > $O/traffic.txt
+rm -rf $O/pmc_fetch $O/pmc_write
+mkdir -p profiles && cp $O/traffic.json profiles/r02_traffic.json      # (in the box's copy: the bench line below reads it)
+python bench.py > $O/bench_line.json 2> $O/bench_line.err
+python bench.py --mode infer --batch 64 > $O/bench_infer_b64.json 2> $O/bench_infer.err
+cat $O/traffic.txt
+head -c 600 $O/bench_line.json
