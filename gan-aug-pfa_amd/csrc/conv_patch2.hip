@@ -53,7 +53,7 @@ struct Patch2K {
     int tiles_y, tiles_x, ntiles, nwg;
     int nss, ssper;          // super-steps in all / per K slice
     int c1chunks;            // 64-channel chunks that come from src1
-    unsigned long long* stamps;   // developer timing (pfa_set_debug_buffer): 4 clock stamps per workgroup, or NULL
+    unsigned long long* stamps;   // developer timing (pfa_set_debug_buffer): 8 clock stamps per workgroup, or NULL
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int qy0 = ty * TY, qx0 = tx * TX, n0 = nt * BN;
     const char* zero = (const char*)g_pfa_zero_page;
     auto stamp = [&](int k) {          // shader clock at four points of the workgroup's life (a separate measurement, never a result)
-        if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 4 + k] = __builtin_amdgcn_s_memtime();
+        if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
 
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
     }
     __syncthreads();
+    stamp(3);
     auto pix_of = [&](int r, bool& valid, size_t& opix) {
         const int qy = qy0 + r / TX, qx = qx0 + r % TX;
         valid = qy < p.hq && qx < p.wq;
@@ -345,10 +346,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         else opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
     };
     const size_t trow = (((size_t)img * q.tiles_y + ty) * q.tiles_x + tx) * (MODE == 0 ? 4 : 1) + cls;
-    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of);
+    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of, q.stamps ? q.stamps + (size_t)blockIdx.x * 8 : nullptr);
     if (q.stamps) {
+        stamp(6);
         __builtin_amdgcn_s_waitcnt(0);  // (stamps only: the stores have been issued AND accepted)
-        stamp(3);
+        stamp(7);
     }
 }
 
@@ -412,7 +414,7 @@ int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, co
     PFA_REQUIRE((q.nss + q.ssper - 1) / q.ssper == plan.splitk, "pfa_conv_patch2: empty K slice");
     q.c1chunks = k.c1 / 64;
     q.stamps = nullptr;
-    if (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 32) q.stamps = (unsigned long long*)g_pfa_dbgbuf;
+    if (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 64) q.stamps = (unsigned long long*)g_pfa_dbgbuf;
     const int sel = (k.mode == PFA_CONV_S2 ? 4 : 0) + (plan.bn == 64 ? 2 : 0) + (plan.tile16 ? 1 : 0);
     static const char* names[8] = {"k_conv_patch2<tconv,128,8x32>", "k_conv_patch2<tconv,128,16x16>", "k_conv_patch2<tconv,64,8x32>",
                                    "k_conv_patch2<tconv,64,16x16>", "k_conv_patch2<conv_s2,128,8x32>", "k_conv_patch2<conv_s2,128,16x16>",

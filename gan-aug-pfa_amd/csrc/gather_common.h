@@ -153,6 +153,7 @@ __device__ __forceinline__ void gather_epilogue(const GatherK& p, f32x4 (&acc)[F
                                                 const int tid, const int split, const size_t trow, char* smem) {
     constexpr int TN = FN * 16;
     const int lane = tid & 63, lrow = lane & 15, kk = lane >> 4;
+    const float neg = act_neg(p.act, p.slope), neg1 = act_neg(p.fuse_act1, p.slope), neg2 = act_neg(p.fuse_act2, p.slope);
 
     if (p.splitk > 1) {
 #pragma unroll
@@ -274,8 +275,8 @@ __device__ __forceinline__ void gather_epilogue(const GatherK& p, f32x4 (&acc)[F
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float y = x[r] * sc[r] + sh[r];
-                    float d = act_grad(y, p.fuse_act1, p.slope) * acc[a][b][r];
-                    if (has_g2) d += act_grad(y, p.fuse_act2, p.slope) * g2[r];
+                    float d = act_grad_lin(y, neg1) * acc[a][b][r];
+                    if (has_g2) d += act_grad_lin(y, neg2) * g2[r];
                     acc[a][b][r] = d;
                     fs[a][r] += d;
                     fq[a][r] += d * ((x[r] - mu[r]) * is[r]);
@@ -360,14 +361,12 @@ __device__ __forceinline__ void gather_epilogue(const GatherK& p, f32x4 (&acc)[F
                 for (int r = 0; r < 4; ++r) {
                     const float t = acc[a][b][r];
                     if (BN == 16 && p.act == PFA_ACT_TANH) v[r] = tanhf(t);          // only the 3-channel output layer
-                    else if (p.act == PFA_ACT_LRELU) v[r] = t >= 0.f ? t : t * p.slope;
-                    else if (p.act == PFA_ACT_RELU) v[r] = t > 0.f ? t : 0.f;
-                    else v[r] = t;
+                    else v[r] = act_lin(t, neg);
                 }
                 store4<T>(obase + (opix[b] * ld + col) * sizeof(T), v);
                 if (p.fuse_out == 3 && p.out2 && col < p.ld2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[a][b][r], p.fuse_act2, p.slope);
+                    for (int r = 0; r < 4; ++r) v[r] = act_lin(acc[a][b][r], neg2);
                     store4<T>(p.out2 + (opix[b] * p.ld2 + col) * sizeof(T), v);
                 }
             }

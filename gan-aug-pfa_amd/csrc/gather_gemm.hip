@@ -667,6 +667,8 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     const size_t plane = (size_t)pixels * n;
     // All passes of the block are loaded together (the pass loop is unrolled, so every pass's read of slice k is in
     // flight at once): a block is latency-, not bandwidth-bound.  The sum over slices stays in ascending k per element.
+    const float neg = act_neg(act, slope), neg2 = act_neg(act2, slope);
+    const float fneg1 = act_neg(fz.act1, slope), fneg2 = act_neg(fz.act2, slope);
     f32x4 v[FIN_PASSES];
     bool live[FIN_PASSES];
 #pragma unroll
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float y = x[e] * sc4[e] + sh4[e];
-                    float d = act_grad(y, fz.act1, slope) * v[ps][e];
-                    if (fz.g2) d += act_grad(y, fz.act2, slope) * g2[e];
+                    float d = act_grad_lin(y, fneg1) * v[ps][e];
+                    if (fz.g2) d += act_grad_lin(y, fneg2) * g2[e];
                     o[e] = d;
                     s[e] += d;
                     q[e] += d * ((x[e] - mu4[e]) * is4[e]);
@@ -712,17 +714,17 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
         if (scale) {
             const f32x4 y = v[ps] * sc4 + sh4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = apply_act(y[e], act, slope);
+            for (int e = 0; e < 4; ++e) o[e] = act_lin(y[e], neg);          // (the affine map is never followed by tanh)
             store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
             if (out2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = apply_act(y[e], act2, slope);
+                for (int e = 0; e < 4; ++e) o[e] = act_lin(y[e], neg2);
                 store4<T>(out2 + (row * ld2 + c0) * sizeof(T), o);
             }
             continue;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = apply_act(v[ps][e], act == PFA_ACT_TANH ? PFA_ACT_NONE : act, slope);
+        for (int e = 0; e < 4; ++e) o[e] = act_lin(v[ps][e], neg);            // (tanh outputs take k_splitk_finish_small)
         if (c0 < n1) store4<T>(out1 + (row * ld1 + c0) * sizeof(T), o);
         else store4<T>(out2 + (row * ld2 + (c0 - n1)) * sizeof(T), o);
     }

@@ -13,9 +13,13 @@
 // Same semantics as gather_epilogue (gather_common.h): K-slice partials, bias, fused backward (fuse_out 1|2), eval-mode
 // affine map with two activation outputs (fuse_out 3), partial statistics, activation, one or two outputs.
 #pragma once
+#include <type_traits>
+
 #include "gather_common.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 __device__ __forceinline__ void load8f(const float* p, bool vec, int limit, float* v) {     // v[e] = p[e] for e < limit
     if (vec) {
@@ -36,7 +40,8 @@ template <int BN> constexpr int patch_image_stride() { return BN * 4 + 16; }
 // patch_image_stride<BN>() and passed a barrier.
 template <int BN, typename PixOf>
 __device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int n0, const int tid, const int split,
-                                                    const size_t trow, char* smem, PixOf pix_of) {
+                                                    const size_t trow, char* smem, PixOf pix_of,
+                                                    unsigned long long* stamps = nullptr) {
     constexpr int RS = patch_image_stride<BN>();
     constexpr int CPR = BN / 8;                  // 16-byte output chunks per row
     constexpr int RPP = 512 / CPR;               // rows per pass
@@ -88,8 +93,9 @@ __device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int 
     }
 
     // ---- the rows, four at a time: operand loads of the fused backward first (in flight together), then arithmetic and
-    //      stores.  (Activations here are LeakyReLU / ReLU / none: the route excludes tanh.)
-    auto act_of = [&](float t, int act) { return act == PFA_ACT_LRELU ? (t >= 0.f ? t : t * p.slope) : act == PFA_ACT_RELU ? (t > 0.f ? t : 0.f) : t; };
+    //      stores.  (Activations here are LeakyReLU / ReLU / none: the route excludes tanh.)  The three kinds of row work
+    //      are compiled as three loops: per-element decisions on launch-wide flags would be scalar branches per element.
+    const float neg = act_neg(p.act, p.slope), neg1 = act_neg(p.fuse_act1, p.slope), neg2 = act_neg(p.fuse_act2, p.slope);
     const bool has_g2 = fused && p.fuse_g2 != nullptr;
     float ss[8], sq[8];
 #pragma unroll
@@ -97,71 +103,97 @@ __device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int 
     const bool stats = p.psum != nullptr;
     constexpr int RB = 4;                        // rows per batch
     static_assert(NP % RB == 0, "row batches");
+    auto rows = [&](auto kind_, auto g2_) {      // KIND 0: bias, statistics, activation; 1: fused backward; 2: affine map, two outputs
+        constexpr int KIND = decltype(kind_)::value;
+        constexpr bool G2 = KIND == 1 && decltype(g2_)::value;
+        constexpr bool PLAIN = KIND == 0 && decltype(g2_)::value;     // KIND 0 without bias and activation (a BatchNorm layer's conv)
 #pragma unroll
-    for (int k0 = 0; k0 < NP; k0 += RB) {
-        bool valid[RB];
-        size_t opix[RB];
-#pragma unroll
-        for (int k = 0; k < RB; ++k) {
-            pix_of(rsub + (k0 + k) * RPP, valid[k], opix[k]);
-            valid[k] = valid[k] && live;
-        }
-        bf16x8 xr[RB], gr[RB];
-        if (fused) {
+        for (int k0 = 0; k0 < NP; k0 += RB) {
+            bool valid[RB];
+            size_t opix[RB];
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
-                const size_t e = valid[k] ? opix[k] * old + ocol : 0;     // (rows without work read element 0: no branch per load)
-                xr[k] = *(const bf16x8*)(p.fuse_raw + e * sizeof(T));
+                pix_of(rsub + (k0 + k) * RPP, valid[k], opix[k]);
+                valid[k] = valid[k] && live;
             }
-            if (has_g2) {
+            bf16x8 xr[RB], gr[RB];
+            if (KIND == 1) {
 #pragma unroll
                 for (int k = 0; k < RB; ++k) {
-                    const size_t e = valid[k] ? opix[k] * old + ocol : 0;
-                    gr[k] = *(const bf16x8*)(p.fuse_g2 + e * sizeof(T));
+                    const size_t e = valid[k] ? opix[k] * old + ocol : 0;     // (rows without work read element 0: no branch per load)
+                    xr[k] = *(const bf16x8*)(p.fuse_raw + e * sizeof(T));
+                    if (G2) gr[k] = *(const bf16x8*)(p.fuse_g2 + e * sizeof(T));
                 }
             }
-        }
 #pragma unroll
-        for (int k = 0; k < RB; ++k) {
-            if (!valid[k]) continue;
-            const char* src = lrd + (k0 + k) * RPP * RS;
-            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
-            float v[8];
+            for (int k = 0; k < RB; ++k) {
+                if (!valid[k]) continue;
+                const char* src = lrd + (k0 + k) * RPP * RS;
+                const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 16);
+                float v[8];
+                if (KIND == 0 && PLAIN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
-            bf16x8 o, o2;
-            if (fused) {
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = (float)xr[k][e];
-                    const float y = x * sc[e] + sh[e];
-                    float d = act_grad(y, p.fuse_act1, p.slope) * v[e];
-                    if (has_g2) d += act_grad(y, p.fuse_act2, p.slope) * (float)gr[k][e];
-                    ss[e] += d;
-                    sq[e] += d * ((x - mu[e]) * is[e]);
-                    o[e] = (bf16_t)d;
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e] + bv[e]; v[4 + e] = hi[e] + bv[4 + e]; }
                 }
-            } else if (p.fuse_out == 3) {
+                bf16x8 o;
+                if (KIND == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float y = v[e] * sc[e] + sh[e];
-                    o[e] = (bf16_t)act_of(y, p.act);
-                    o2[e] = (bf16_t)act_of(y, p.fuse_act2);
-                }
-                if (p.out2 && col < p.ld2) *(bf16x8*)(p.out2 + (opix[k] * p.ld2 + col) * sizeof(T)) = o2;
-            } else {
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = (float)xr[k][e];
+                        const float y = x * sc[e] + sh[e];
+                        float d = act_grad_lin(y, neg1) * v[e];
+                        if (G2) d += act_grad_lin(y, neg2) * (float)gr[k][e];
+                        ss[e] += d;
+                        sq[e] += d * ((x - mu[e]) * is[e]);
+                        o[e] = (bf16_t)d;
+                    }
+                } else if (KIND == 2) {
+                    bf16x8 o2;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    ss[e] += v[e];
-                    sq[e] += v[e] * v[e];
-                    o[e] = (bf16_t)act_of(v[e], p.act);
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = v[e] * sc[e] + sh[e];
+                        o[e] = (bf16_t)act_lin(y, neg);
+                        o2[e] = (bf16_t)act_lin(y, neg2);
+                    }
+                    if (p.out2 && col < p.ld2) *(bf16x8*)(p.out2 + (opix[k] * p.ld2 + col) * sizeof(T)) = o2;
+                } else {
+                    // (pairs: v_pk_add_f32 / v_pk_fma_f32 - this loop is VALU-bound, 8 elements x 8 rows a thread)
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f32x2 v2 = {v[e], v[e + 1]};
+                        f32x2 s2 = {ss[e], ss[e + 1]}, q2 = {sq[e], sq[e + 1]};
+                        s2 += v2;
+                        q2 = __builtin_elementwise_fma(v2, v2, q2);
+                        ss[e] = s2[0]; ss[e + 1] = s2[1]; sq[e] = q2[0]; sq[e + 1] = q2[1];
+                    }
+                    if (PLAIN) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)act_lin(v[e], neg);
+                    }
                 }
+                *(bf16x8*)(obase + (opix[k] * old + ocol) * sizeof(T)) = o;
             }
-            *(bf16x8*)(obase + (opix[k] * old + ocol) * sizeof(T)) = o;
         }
+    };
+    if (fused) {
+        if (has_g2) rows(std::integral_constant<int, 1>{}, std::true_type{});
+        else rows(std::integral_constant<int, 1>{}, std::false_type{});
+    } else if (p.fuse_out == 3) {
+        rows(std::integral_constant<int, 2>{}, std::false_type{});
+    } else if (p.bias == nullptr && neg == 1.f) {
+        rows(std::integral_constant<int, 0>{}, std::true_type{});
+    } else {
+        rows(std::integral_constant<int, 0>{}, std::false_type{});
     }
 
     // ---- partial statistics of this tile: lanes that share a chunk column inside a wave (lane % CPR), then the 8 waves
+    if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memtime();       // (developer timing: rows issued)
     if (!stats) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -171,6 +203,7 @@ __device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int 
             sq[e] += __shfl_xor(sq[e], off);
         }
     }
+    if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();       // (shuffles done)
     __syncthreads();                             // the fp32 image has been consumed
     float* red = (float*)smem;                   // [8 waves][2][BN]
     const int wave = tid >> 6;

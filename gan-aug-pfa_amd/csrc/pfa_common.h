@@ -114,22 +114,18 @@ template <> struct Chunk<bf16_t> {
     }
 };
 
+// The piecewise-linear activations are ONE select with a uniform coefficient: act(v) = v > 0 ? v : neg * v, act'(y) = y > 0 ? 1 : neg
+// (LeakyReLU: neg = slope, ReLU: 0, none: 1).  A `switch (act)` per element compiles to scalar branches per element - the
+// whole-row epilogues spent most of their time in them; kernels hoist act_neg() out of their element loops.
+__device__ __forceinline__ float act_neg(int act, float slope) { return act == PFA_ACT_LRELU ? slope : act == PFA_ACT_RELU ? 0.f : 1.f; }
+__device__ __forceinline__ float act_lin(float v, float neg) { return v > 0.f ? v : v * neg; }
+__device__ __forceinline__ float act_grad_lin(float y, float neg) { return y > 0.f ? 1.f : neg; }
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
-    switch (act) {
-        case PFA_ACT_LRELU: return v >= 0.f ? v : v * slope;
-        case PFA_ACT_RELU: return v > 0.f ? v : 0.f;
-        case PFA_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
+    if (act == PFA_ACT_TANH) return tanhf(v);
+    return act_lin(v, act_neg(act, slope));
 }
 // derivative of the activation evaluated at its INPUT y (torch: x > 0 ? g : g*slope)
-__device__ __forceinline__ float act_grad(float y, int act, float slope) {
-    switch (act) {
-        case PFA_ACT_LRELU: return y > 0.f ? 1.f : slope;
-        case PFA_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        default: return 1.f;
-    }
-}
+__device__ __forceinline__ float act_grad(float y, int act, float slope) { return act_grad_lin(y, act_neg(act, slope)); }
 
 // XCD-aware work-item id (cdna guide T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs,
 // each with a private L2: give every XCD one CONTIGUOUS chunk of the work list so that workgroups which share an

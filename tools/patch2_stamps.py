@@ -22,8 +22,8 @@ L = [
  ("e3/c3 dgrad", K.TCONV_S2, (32, 32, [256]), 128, (32, 32)),
 ]
 lib = _lib.lib()
-buf = torch.zeros(8192 * 4, dtype=torch.int64, device='cuda')
-print(f"{'layer':14s} {'wgs':>5s} {'event us':>9s} | cycles (median over workgroups): prologue   loop  epilogue  total | start spread  end spread (cycles)")
+buf = torch.zeros(8192 * 8, dtype=torch.int64, device='cuda')
+print(f"{'layer':14s} {'wgs':>5s} {'event us':>9s} | median cycles: prologue    loop  to-LDS    rows shuffle  reduce   drain |   total")
 for name, mode, (h, w, cs), n, (hq, wq) in L:
     srcs = [T(B, h, w, c) for c in cs]
     wgt = T(n, 16, sum(cs))
@@ -40,9 +40,12 @@ for name, mode, (h, w, cs), n, (hq, wq) in L:
     K.gather_gemm(mode, srcs, wgt, n, [o], (B, hq, wq), ws, stats=stats)
     e1.record(); torch.cuda.synchronize()
     lib.pfa_set_debug_buffer(None, 0)
-    st = buf.view(-1, 4).cpu()
-    st = st[st[:, 3] != 0]
+    st = buf.view(-1, 8).cpu()
+    st = st[st[:, 7] != 0]
     d = st.double()
-    pro, loop, epi, tot = (d[:, 1] - d[:, 0]).median(), (d[:, 2] - d[:, 1]).median(), (d[:, 3] - d[:, 2]).median(), (d[:, 3] - d[:, 0]).median()
-    print(f"{name:14s} {st.shape[0]:5d} {e0.elapsed_time(e1)*1e3:9.1f} | {pro:10.0f} {loop:7.0f} {epi:8.0f} {tot:7.0f} | "
-          f"{(d[:, 0].max() - d[:, 0].min()):10.0f} {(d[:, 3].max() - d[:, 3].min()):10.0f}   span {(d[:, 3].max() - d[:, 0].min()):8.0f}")
+    seg = [(d[:, k + 1] - d[:, k]) for k in range(7)]
+    if not stats:       # stamps 5 is not written without statistics
+        seg[4] = d[:, 6] - d[:, 4]; seg[5] = seg[4] * 0
+    med = [float(x.median()) for x in seg]
+    tot = float((d[:, 7] - d[:, 0]).median())
+    print(f"{name:14s} {st.shape[0]:5d} {e0.elapsed_time(e1)*1e3:9.1f} | " + " ".join(f"{m:7.0f}" for m in med) + f" | {tot:7.0f}")
