@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as three captured hipGraphs (default: eager launches on three HIP streams, which "
                          "measured faster: the graph executor does not run the forked side-stream branch concurrently)")
+    ap.add_argument("--replay", action="store_true",
+                    help="GanTrainer(use_graph='replay'): the step's launches recorded once as launch lists and re-issued "
+                         "from C (pfa_replay) on the same three streams")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
     ap.add_argument("--no-early-real", action="store_true",
@@ -381,7 +384,7 @@ def main():
     gen = pfa_gan.UNetGenerator(3, 3).cuda()
     disc = pfa_gan.NLayerDiscriminator(6).cuda()
     # inputs_resident: the batches below are packed and complete in HBM before the first step (the bench contract)
-    trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph="auto" if args.auto_graph else args.graph,
+    trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph="auto" if args.auto_graph else ("replay" if args.replay else args.graph),
                                  overlap=not args.no_overlap, inputs_resident=not args.no_early_real)
     if world > 1:                                    # rank 0's parameters and buffers are the job's
         for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
@@ -441,7 +444,8 @@ def main():
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph x3 segments" if trainer.use_graph is True else
-                                 ("eager, 3 HIP streams" if not args.no_overlap else "eager, 1 HIP stream"),
+                                 (("launch lists (pfa_replay), " if trainer.use_graph == "replay" else "eager, ") +
+                                  ("3 HIP streams" if not args.no_overlap else "1 HIP stream")),
                        "timing": f"median of {len(reps)} repeats of {args.steps} steps",
                        "last_losses": [round(l, 4) for l in losses]},
         }

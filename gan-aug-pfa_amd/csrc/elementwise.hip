@@ -859,3 +859,18 @@ extern "C" int pfa_fill_zero(void* p, size_t bytes, pfa_stream s) {
     if (e != hipSuccess) PFA_FAIL((int)e, "pfa_fill_zero: %s", hipGetErrorString(e));
     return 0;
 }
+
+namespace {
+__global__ void k_axpy(float* __restrict__ y, const float* __restrict__ x, int64_t n, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+}  // namespace
+
+extern "C" int pfa_axpy(float* y, const float* x, int64_t n, float alpha, pfa_stream s) {
+    PFA_REQUIRE((y && x) || n == 0, "pfa_axpy: null");
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(k_axpy, dim3(blocks), dim3(256), 0, (hipStream_t)s, y, x, n, alpha);
+    PFA_LAUNCHED("k_axpy");
+    return 0;
+}

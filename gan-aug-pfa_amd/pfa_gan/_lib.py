@@ -109,7 +109,17 @@ PROTOTYPES = {
     "pfa_unpack_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_unpack_u8": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pfa_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "pfa_axpy": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "pfa_replay_index": (c_int, [c_char_p]),
+    "pfa_replay": (c_int, [c_void_p, c_int, POINTER(c_int)]),
 }
+
+
+class ReplayOp(Structure):
+    _fields_ = [("kind", c_int32), ("fn", c_int32), ("a", c_void_p), ("b", c_void_p)]
+
+
+OP_CALL, OP_RECORD, OP_WAIT = 0, 1, 2
 
 _LIB = None
 
@@ -134,7 +144,126 @@ def lib():
         for item in filter(None, os.environ.get("PFA_KNOBS", "").split(",")):   # e.g. PFA_KNOBS=0=5 (A/B runs)
             k, v = item.split("=")
             handle.pfa_set_knob(int(k), int(v))
+    if _RECORDER is not None:
+        return _RECORDER.proxy
     return _LIB
+
+
+# ------------------------------------------------------------------------------------ launch lists (pfa_replay)
+_RECORDER = None
+
+
+class LaunchList:
+    """A recorded sequence of library calls, event records and stream waits; replay() re-issues it with one C call."""
+
+    def __init__(self, ops, keep):
+        self.n = len(ops)
+        self.ops = (ReplayOp * max(self.n, 1))(*ops)
+        self._keep = keep               # argument blocks, struct copies, events, streams: alive as long as the list
+        self.calls = sum(1 for o in ops if o.kind == OP_CALL)
+
+    def replay(self):
+        failed = c_int(-1)
+        rc = _LIB.pfa_replay(ctypes.addressof(self.ops), self.n, ctypes.byref(failed))
+        if rc != 0:
+            msg = _LIB.pfa_last_error_string().decode(errors="replace")
+            raise PfaError(f"pfa_replay failed at op {failed.value} (rc={rc}): {msg}")
+
+
+class _Proxy:
+    """Stands in for the library while a Recorder is active: every launching entry point is called AND noted."""
+
+    def __init__(self, rec):
+        self._rec = rec
+
+    def __getattr__(self, name):
+        fn = getattr(_LIB, name)
+        idx = self._rec.index(name)
+        if idx < 0:
+            return fn
+        rec = self._rec
+
+        def call(*args):
+            rc = fn(*args)
+            if rc == 0:
+                rec.note_call(name, idx, args)
+            return rc
+        return call
+
+
+class Recorder:
+    """with Recorder() as r: ...launches...; r.finish() -> LaunchList.  The launches run normally while they are recorded.
+    Streams are taken from the calls themselves; event records / stream waits between streams must go through
+    kernels.record_event / wait_event / wait_stream, which note them here."""
+
+    _structs = {}
+
+    def __init__(self):
+        self.ops, self.keep = [], []
+        self._idx = {}
+        self.proxy = _Proxy(self)
+
+    def __enter__(self):
+        global _RECORDER
+        lib()
+        if _RECORDER is not None:
+            raise PfaError("a launch list is already being recorded")
+        _RECORDER = self
+        return self
+
+    def __exit__(self, *exc):
+        global _RECORDER
+        _RECORDER = None
+        return False
+
+    def index(self, name):
+        if name not in self._idx:
+            self._idx[name] = _LIB.pfa_replay_index(name.encode()) if name in PROTOTYPES else -1
+        return self._idx[name]
+
+    @classmethod
+    def _arg_struct(cls, name):
+        st = cls._structs.get(name)
+        if st is None:
+            fields = []
+            for i, t in enumerate(PROTOTYPES[name][1]):
+                is_ptr = isinstance(t, type) and issubclass(t, ctypes._Pointer)
+                fields.append((f"a{i}", c_void_p if is_ptr else t))
+            st = type(f"Args_{name}", (Structure,), {"_fields_": fields})
+            cls._structs[name] = st
+        return st
+
+    def note_call(self, name, idx, args):
+        st = self._arg_struct(name)()
+        for i, (t, v) in enumerate(zip(PROTOTYPES[name][1], args)):
+            if isinstance(t, type) and issubclass(t, ctypes._Pointer):
+                if v is None:
+                    v = None
+                else:
+                    obj = getattr(v, "_obj", None)          # ctypes.byref(x)
+                    if obj is None:
+                        raise PfaError(f"{name}: argument {i} cannot be recorded (pass ctypes.byref of a ctypes object)")
+                    copy = type(obj).from_buffer_copy(obj)
+                    self.keep.append(copy)
+                    v = ctypes.addressof(copy)
+            setattr(st, f"a{i}", v)
+        self.keep.append(st)
+        self.ops.append(ReplayOp(OP_CALL, idx, ctypes.addressof(st), None))
+
+    def note_record(self, event, stream):
+        self.keep += [event, stream]
+        self.ops.append(ReplayOp(OP_RECORD, 0, event.cuda_event, stream.cuda_stream))
+
+    def note_wait(self, stream, event):
+        self.keep += [event, stream]
+        self.ops.append(ReplayOp(OP_WAIT, 0, event.cuda_event, stream.cuda_stream))
+
+    def finish(self):
+        return LaunchList(self.ops, self.keep)
+
+
+def recorder():
+    return _RECORDER
 
 
 def check(rc, what=""):

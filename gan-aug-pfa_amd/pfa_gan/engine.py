@@ -199,7 +199,7 @@ class _Engine:
         if side is None:
             fn(self.ws_cur)
             return
-        side.wait_stream(torch.cuda.current_stream())
+        K.wait_stream(side, torch.cuda.current_stream())
         with torch.cuda.stream(side):
             fn(self.ws_side)
 

@@ -47,6 +47,37 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Event records / stream waits between the step's streams: the torch call, noted when a launch list is being recorded.
+def record_event(event, st):
+    event.record(st)
+    rec = _lib.recorder()
+    if rec is not None:
+        rec.note_record(event, st)
+
+
+def wait_event(st, event):
+    st.wait_event(event)
+    rec = _lib.recorder()
+    if rec is not None:
+        rec.note_wait(st, event)
+
+
+def wait_stream(dst, src):
+    """dst.wait_stream(src)"""
+    rec = _lib.recorder()
+    if rec is None:
+        dst.wait_stream(src)
+        return
+    ev = torch.cuda.Event()
+    record_event(ev, src)
+    wait_event(dst, ev)
+
+
+def axpy(y, x, alpha=1.0):
+    """y += alpha * x (float32, same length) on the current stream."""
+    check(lib().pfa_axpy(ptr(y), ptr(x), y.numel(), float(alpha), stream()), "pfa_axpy")
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 

@@ -11,6 +11,7 @@ import math
 import torch
 
 from . import kernels as K
+from . import _lib
 from ._lib import PfaError
 from .engine import FlatParams
 from .models import resolve_dtype
@@ -137,7 +138,9 @@ class GanTrainer:
         device memory before the call - e.g. a pool of resident batches, or batches produced on a stream the caller
         has synchronised.  The D(real) pass of a step then no longer waits for the previous step's generator update
         (see _d_phase).
-        use_graph: False = eager launch on three streams (the measured configuration); True = the step's three segments
+        use_graph: False = eager launch on three streams from Python; "replay" = the same launches, streams and
+        dependencies recorded once per segment as launch lists and re-issued from C (pfa_replay): the host cost of a
+        step drops from ~2.5 ms to ~0.2 ms, static shapes and addresses as for graphs; True = the step's three segments
         replayed as captured hipGraphs; "auto" = hipGraph replay on ONE stream when the first batch is tiny (at most
         AUTO_GRAPH_PIXELS = 2 x 256 x 256 pixels per GPU: the reference's own BATCH_SIZE = 1, train_gan.py:26, where the
         step is launch-latency bound and the replay is 26 % faster than eager), eager otherwise."""
@@ -174,6 +177,8 @@ class GanTrainer:
         self.inputs_resident = bool(inputs_resident)
         self._loss_real = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = None
+        self._listing = False          # launch lists are being warmed up / recorded / replayed (use_graph == "replay")
+        self._ev_static = torch.cuda.Event() if overlap else None      # the static input copies of a replayed step are complete
         self._static = None
         self._graph_one_stream = False
         self.G.refresh_shadows(force=True)
@@ -209,12 +214,13 @@ class GanTrainer:
         # later than the side stream may already have added to it) and its gradient arena is zeroed on the side stream.
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
-        if (self.inputs_resident or ready is not None) and self._d_free_recorded and not graph_safe:
-            self.side.wait_event(self._ev_d_free)
+        # (a captured hipGraph cannot wait for an event of another graph; a launch list can: it re-issues the same waits)
+        if (self.inputs_resident or ready is not None) and self._d_free_recorded and (not graph_safe or self._listing):
+            K.wait_event(self.side, self._ev_d_free)
             if ready is not None:
-                self.side.wait_event(ready)
+                K.wait_event(self.side, ready)
         else:
-            self.side.wait_stream(main)
+            K.wait_stream(self.side, main)
         K.fill_zero(garena)
         with torch.cuda.stream(self.side):
             K.fill_zero(garena2)
@@ -222,17 +228,17 @@ class GanTrainer:
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
             K.bce_logits(lr, 1.0, 0.5, 0.5, self._loss_real, dl_r)
-            self._ev_real_fwd.record(self.side)
+            K.record_event(self._ev_real_fwd, self.side)
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True)
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
-        main.wait_event(self._ev_real_fwd)
+        K.wait_event(main, self._ev_real_fwd)
         lf = Dn.forward([xa, fake], self.ctx_f, train=True)
         dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
         K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
         Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side2)
-        main.wait_stream(self.side)
-        main.wait_stream(self.side2)
-        self.losses[0:1].add_(self._loss_real)
+        K.wait_stream(main, self.side)
+        K.wait_stream(main, self.side2)
+        K.axpy(self.losses[0:1], self._loss_real)
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
@@ -244,8 +250,8 @@ class GanTrainer:
         dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
         K.bce_logits(lg, 1.0, 1.0, 1.0, self.losses[1:2], dl_g)
         dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
-        if self._ev_d_free is not None and not graph_safe:
-            self._ev_d_free.record(torch.cuda.current_stream())    # the next step's D(real) may start from here
+        if self._ev_d_free is not None and (not graph_safe or self._listing):
+            K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
         K.l1_tanh_bwd(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self.losses[1:2], dpre)
@@ -268,8 +274,8 @@ class GanTrainer:
                 lo, hi = buckets[i]
                 if hi <= lo:
                     return
-                self.side2.wait_stream(main)
-                self.side2.wait_stream(self.side)
+                K.wait_stream(self.side2, main)
+                K.wait_stream(self.side2, self.side)
                 with torch.cuda.stream(self.side2):
                     if self.pg is not None:
                         # enqueued behind side2, runs on the communicator's stream; side2 (not the weight-gradient
@@ -285,14 +291,14 @@ class GanTrainer:
                 lo, hi = buckets[i]
                 if hi <= lo:
                     return
-                self.side.wait_stream(main)
+                K.wait_stream(self.side, main)
                 with torch.cuda.stream(self.side):
                     self._works.append(torch.distributed.all_reduce(garena[lo:hi], group=self.pg, async_op=True))
         G.backward(self.gctx, dpre, garena, side=self.side, bucket_ready=hook)
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:
-            torch.cuda.current_stream().wait_stream(self.side2)
+            K.wait_stream(torch.cuda.current_stream(), self.side2)
             G.shadows_refreshed()
         for w in self._works:
             w.wait()                 # the current stream waits for the collective; no host sync
@@ -305,7 +311,7 @@ class GanTrainer:
         else:
             self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
             self.G.refresh_shadows(force=True)
-        self.loss_sums += self.losses
+        K.axpy(self.loss_sums, self.losses)
 
     def _allreduce(self, opt):
         if self.pg is not None:
@@ -363,6 +369,8 @@ class GanTrainer:
             self.side = side
 
     def _step_graph_inner(self, xa, xb):
+        self._listing = self.use_graph == "replay" and self.side is not None
+        ready = self._ev_static if self._listing else None
         if self._graphs is None:
             self._static = (torch.empty_like(xa), torch.empty_like(xb))
             sa, sb = self._static
@@ -372,26 +380,30 @@ class GanTrainer:
             for o in (self.opt_g, self.opt_d):    # outside the capture: a captured fill would reset the counter on every replay
                 o.sync_step_dev()
             state = self._snapshot()
+            if ready is not None:
+                ready.record(torch.cuda.current_stream())
             for _ in range(2):
-                self._d_phase(sa, sb, True)
+                self._d_phase(sa, sb, True, ready)
                 self._d_update_g_phase(sa, sb, True)
                 self._g_update(True)
             self._restore(state)
             torch.cuda.synchronize()
             segs = []
-            for fn in (lambda: self._d_phase(sa, sb, True), lambda: self._d_update_g_phase(sa, sb, True),
+            for fn in (lambda: self._d_phase(sa, sb, True, ready), lambda: self._d_update_g_phase(sa, sb, True),
                        lambda: self._g_update(True)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fn()
-                segs.append(g)
+                segs.append(self._capture(fn))
             self._restore(state)
             self._graphs = segs
+            self._capture_stream = torch.cuda.current_stream().cuda_stream
+        if self.use_graph == "replay" and torch.cuda.current_stream().cuda_stream != self._capture_stream:
+            raise PfaError("GanTrainer(use_graph='replay'): the launch lists were recorded on another current stream")
         sa, sb = self._static
         sa.copy_(xa)
         sb.copy_(xb)
         for o in (self.opt_g, self.opt_d):        # an eager step since the last replay moved only the host count
             o.sync_step_dev()
+        if ready is not None:                     # the side stream's D(real) waits for this, not for the previous step's tail
+            ready.record(torch.cuda.current_stream())
         self._graphs[0].replay()
         self._allreduce(self.opt_d)
         self._graphs[1].replay()
@@ -406,6 +418,19 @@ class GanTrainer:
         self.Dn.bn_epoch += 1
         self.nsteps += 1
         return self.losses
+
+    def _capture(self, fn):
+        """One segment of the step as an object with .replay(): a captured hipGraph, or - use_graph == "replay" - a launch
+        list (pfa_replay): the segment's library calls, event records and stream waits recorded while it runs once, then
+        re-issued from C on the same streams (the hipGraph executor serialises the forked branches; this does not)."""
+        if self.use_graph == "replay":
+            with _lib.Recorder() as rec:
+                fn()
+            return rec.finish()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
 
     def _snapshot(self):
         bufs = [b for m in (self.gen, self.disc) for b in m.buffers()]

@@ -311,6 +311,29 @@ int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dty
 int pfa_unpack_u8(const void* src, int64_t pixels, int c, int cp, int dtype, float mul, float add, uint8_t* dst,
                   pfa_stream s);
 int pfa_fill_zero(void* p, size_t bytes, pfa_stream s);
+/* y[i] += alpha * x[i], float32 (loss bookkeeping of train_gan.py:63,71,74-75 kept on the device). */
+int pfa_axpy(float* y, const float* x, int64_t n, float alpha, pfa_stream s);
+
+/* ------------------------------------------------------------------ launch lists
+ * A training step is ~210 launches on three streams with the same arguments every iteration (static shapes, persistent
+ * buffers).  Issuing them from Python costs ~2.5 ms per step; a launch list is that sequence recorded once - every call of
+ * an entry point above with its argument values, plus the event records / stream waits between the streams - and re-issued
+ * by ONE call.  (hipGraph replay of the same fork/join pattern serialises the branches; this keeps the three streams.)
+ *   PFA_OP_CALL    fn = pfa_replay_index(name); a = the call's arguments laid out as a C struct in declaration order
+ *                  (natural alignment; a pointer-to-struct argument points at a caller-kept copy of that struct)
+ *   PFA_OP_RECORD  hipEventRecord((hipEvent_t)a, (hipStream_t)b)
+ *   PFA_OP_WAIT    hipStreamWaitEvent((hipStream_t)b, (hipEvent_t)a)
+ * pfa_replay issues ops[0..n) in order on the calling thread; on a failing op it stops, stores its index in *failed_at (if
+ * given) and returns that op's return code.  The caller keeps every buffer, stream and event of the list alive. */
+enum { PFA_OP_CALL = 0, PFA_OP_RECORD = 1, PFA_OP_WAIT = 2 };
+typedef struct pfa_replay_op {
+    int32_t kind;
+    int32_t fn;
+    const void* a;
+    void* b;
+} pfa_replay_op;
+int pfa_replay_index(const char* name);       /* -1: not a launching entry point */
+int pfa_replay(const pfa_replay_op* ops, int n, int* failed_at);
 
 #ifdef __cplusplus
 }

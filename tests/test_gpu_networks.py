@@ -171,10 +171,11 @@ def _check_step_state(z, name, G, D, tol_param=2e-5):
                 assert_close(v, want, 1e-5, 2e-3, f"{prefix} buffer {k}")
 
 
-@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipgraph"])
+@pytest.mark.parametrize("use_graph", [False, True, "replay"], ids=["eager", "hipgraph", "launch_lists"])
 @pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
 def test_fused_step_fp32_vs_reference(golden, case, use_graph):
-    """Two consecutive train_gan_one_epoch iterations of the reference vs GanTrainer (fused schedule)."""
+    """Two consecutive train_gan_one_epoch iterations of the reference vs GanTrainer (fused schedule): launched from
+    Python, replayed as hipGraphs, and re-issued from C as launch lists (pfa_replay) on the three streams."""
     name, nd, ngf, ndf, n, h, steps = case
     z = golden("step")
     G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
@@ -877,3 +878,37 @@ def test_eval_caches_follow_parameter_and_buffer_writes(precision):
         sd = {k: v.clone() for k, v in G.state_dict().items()}
         G.load_state_dict(sd)
         assert torch.equal(G(x), y3)
+
+
+def test_launch_list_records_calls_events_and_replays():
+    """pfa_replay: library calls on two streams with an event between them, recorded once (they also run), re-issued by one
+    C call; a struct argument is deep-copied; a failing op reports its index."""
+    from pfa_gan import kernels as K
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    x = torch.arange(1024, dtype=torch.float32, device="cuda")
+    y = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    z = torch.zeros(1024, dtype=torch.float32, device="cuda")
+    ev = torch.cuda.Event()
+    before = _lib.launch_count()
+    with _lib.Recorder() as rec:
+        K.wait_stream(side, main)
+        with torch.cuda.stream(side):
+            K.fill_zero(y)
+            K.axpy(y, x, 2.0)                    # y = 2x on the side stream
+            K.record_event(ev, side)
+        K.wait_event(main, ev)
+        K.axpy(z, y, 0.5)                        # z += x on the main stream, after the side stream's work
+        assert K.ch_of(torch.bfloat16) == 8      # (a non-launching call passes through)
+    ll = rec.finish()
+    assert ll.calls == 3 and ll.n == 3 + 4       # fill, 2 axpy; wait_stream = record + wait, record, wait
+    torch.cuda.synchronize()
+    assert torch.equal(z, x)                     # the recording run executed
+    for _ in range(3):
+        ll.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(z, 4 * x) and torch.equal(y, 2 * x)
+    assert _lib.launch_count() - before == 2 * 4         # (fill_zero is a memset, not a kernel launch)
+    # a bad op: the list stops there and says where
+    bad = _lib.LaunchList([_lib.ReplayOp(_lib.OP_CALL, 9999, 1, None)], [])
+    with pytest.raises(_lib.PfaError, match="op 0"):
+        bad.replay()
