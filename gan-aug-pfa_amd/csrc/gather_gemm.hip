@@ -885,6 +885,9 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
                     a->fuse_act2 != PFA_ACT_TANH,
                     "pfa_gather_gemm: the affine epilogue writes all columns to out1 (n1 >= n), without bias, statistics or tanh");
         PFA_REQUIRE(a->out2 == nullptr || a->ld2 == a->ld1, "pfa_gather_gemm: affine epilogue outputs must share one row length");
+    } else if (a->fuse_out == PFA_FUSE_DEFER) {
+        PFA_REQUIRE(k.splitk > 1 && a->slab && a->bias == nullptr && a->act == PFA_ACT_NONE && a->psum == nullptr && a->n % 4 == 0,
+                    "pfa_gather_gemm: PFA_FUSE_DEFER leaves K-slice partial planes: it needs splitk > 1, a slab, n %% 4 == 0 and no bias / activation / statistics");
     } else if (a->fuse_out) {
         PFA_REQUIRE(a->fuse_out == 1 || (a->fuse_out == 2 && a->ld2 > 0), "pfa_gather_gemm: fuse_out must name an existing output");
         PFA_REQUIRE(a->fuse_raw && (a->fuse_scale == nullptr) == (a->fuse_shift == nullptr) &&
@@ -896,7 +899,7 @@ int fill_params(const pfa_gather_args* a, GatherK& k, int& classes) {
     k.slab_ld = (a->n + 3) & ~3;
     if (k.splitk > 1) PFA_REQUIRE(a->slab, "pfa_gather_gemm: split-K needs a slab of pfa_gather_slab_floats() floats");
     PFA_REQUIRE(a->act != PFA_ACT_TANH || a->n <= 16, "pfa_gather_gemm: tanh epilogue is only built for n <= 16");
-    PFA_REQUIRE(!(a->fuse_out && k.splitk > 1) || (finish_vec_ok(a->n, a->n1, a->ld1, a->act) && k.slab_ld == a->n),
+    PFA_REQUIRE(!(a->fuse_out && a->fuse_out != PFA_FUSE_DEFER && k.splitk > 1) || (finish_vec_ok(a->n, a->n1, a->ld1, a->act) && k.slab_ld == a->n),
                 "pfa_gather_gemm: a fused epilogue of a K-sliced launch needs n %% 4 == 0, n/4 dividing 256 (and ld1 == n for one output)");
     // geometry sanity: the source grid must be what the mode implies
     if (a->mode == PFA_CONV_S2) PFA_REQUIRE(a->hs == 2 * a->hq && a->ws == 2 * a->wq, "pfa_gather_gemm: CONV_S2 needs hs=2*hq");
@@ -1178,12 +1181,16 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     PFA_REQUIRE(!(a->fuse_out == 1 || a->fuse_out == 2) || (a->fuse_mean != nullptr) == (a->psum != nullptr),
                 "pfa_gather_gemm: a fused BatchNorm backward needs psum/psq, a fused activation backward must not pass them");
     hipStream_t st = (hipStream_t)s;
+    // PFA_FUSE_DEFER: the K slices stay in the slab for a finish of the caller's (pfa_finish_bn_*): the implicit GEMM runs
+    // them (the small maps this is for are its launches anyway)
+    const bool defer = a->fuse_out == PFA_FUSE_DEFER;
+    if (defer) k.fuse_out = 0;
     int ptiles = 0;
-    const bool patch = patch_route(a, k, &ptiles);
+    const bool patch = !defer && patch_route(a, k, &ptiles);
     int itiles = 0;
-    const bool image = !patch && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles);
+    const bool image = !defer && !patch && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles);
     Patch2Plan plan2;
-    const bool patch2 = !patch && !image && pfa_conv_patch2_plan(k, a->dtype, &plan2);
+    const bool patch2 = !defer && !patch && !image && pfa_conv_patch2_plan(k, a->dtype, &plan2);
     if (patch2) k.splitk = plan2.splitk;          // never more slices than the caller sized the slab for
     const TileCfg cfg = choose_cfg(k);
     int rc;
@@ -1221,6 +1228,11 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         pfa_timing_end(st, te0, te1, g_last_gather_name, flop, bytes, k.splitk);
     }
     if (rc) return rc;
+    if (defer) {
+        a->ntiles_stat = 0;
+        a->splitk = k.splitk;                      // the planes actually written (no empty slices)
+        return 0;
+    }
     if (k.splitk > 1) {
         int tiles = 0;
         // split outputs: slab columns [0,n) -> out1 [0,n1) / out2; a single output passes n1 >= n

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(PKG_DIR, "lib", "libpfa_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 CONV_S2, CONV_S1, TCONV_S2, CONV_S1_DGRAD = 0, 1, 2, 3
+FUSE_DEFER = 4
 
 
 class GatherArgs(Structure):
@@ -110,6 +111,13 @@ PROTOTYPES = {
     "pfa_unpack_u8": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),
     "pfa_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
     "pfa_axpy": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "pfa_finish_bn_supported": (c_int, [c_int, c_int, c_int]),
+    "pfa_finish_bn_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "pfa_finish_bn_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                  c_void_p]),
     "pfa_replay_index": (c_int, [c_char_p]),
     "pfa_replay": (c_int, [c_void_p, c_int, POINTER(c_int)]),
 }

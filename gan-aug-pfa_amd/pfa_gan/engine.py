@@ -311,6 +311,41 @@ class _Engine:
                 ctx.v[tag + ".evalkey"] = key
         return scale, shift
 
+    def _conv_bn_act(self, mode, srcs, L, ctx, tag, raw, grid, train, repeats, out_l, out_r):
+        """raw = conv(srcs); BatchNorm (batch statistics when train); out_l = LeakyReLU(y), out_r = ReLU(y) (either may be
+        None).  A K-sliced launch on a small map is finished over the whole batch in one launch (K.finish_bn_fwd) instead
+        of finish pass + bn_finalize + bn_act."""
+        count = raw.shape[0] * raw.shape[1] * raw.shape[2]
+        if train and K.defer_ok(mode, srcs, L.cout, grid, count):
+            f32, c = torch.float32, L.cout
+            slab, planes = K.gather_gemm(mode, srcs, L.w_fwd, L.cout, [raw], grid, self.ws, defer=True)
+            self.bn_epoch += 1
+            K.finish_bn_fwd(slab, planes, c, L.bn, repeats, raw, out_l, out_r,
+                            ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32),
+                            ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32))
+            return
+        st = K.gather_gemm(mode, srcs, L.w_fwd, L.cout, [raw], grid, self.ws, stats=train)
+        scale, shift = self._bn_coeffs(L, ctx, tag, st, count, train, repeats)
+        K.bn_act(raw, scale, shift, out_l, out_r)
+
+    def _dgrad_fused(self, mode, d, w, n, outs, grid, L, ctx, tag, which, raw, act1, garena, g2=None, act2=K.ACT_NONE,
+                     param_grads=True):
+        """Input-gradient launch whose output `which` (1 | 2 of outs) is the gradient of node `tag` (layer L): fused with
+        the node's activation / BatchNorm backward.  Returns the node's conv-output gradient (= outs[which - 1])."""
+        dy = outs[which - 1]
+        count = dy.shape[0] * dy.shape[1] * dy.shape[2]
+        spec = self._fuse_spec(L, ctx, tag, which, raw, act1, g2, act2)
+        if K.defer_ok(mode, [d], n, grid, count) and (which == 1 or outs[0].shape[3] % 16 == 0) and dy.shape[3] == n - (
+                outs[0].shape[3] if which == 2 else 0):
+            slab, planes = K.gather_gemm(mode, [d], w, n, outs, grid, self.ws_cur, defer=True)
+            bn = L.bn
+            K.finish_bn_bwd(slab, planes, n, outs[0] if which == 2 else None, spec, bn.weight if bn is not None else None,
+                            self.flat.seg(garena, bn.weight) if bn is not None and param_grads else None,
+                            self.flat.seg(garena, bn.bias) if bn is not None and param_grads else None, dy)
+            return dy
+        st = K.gather_gemm(mode, [d], w, n, outs, grid, self.ws_cur, fuse=spec)
+        return self._finish_fused(L, ctx, tag, raw, count, garena, dy, st, param_grads=param_grads)
+
     def _bn_backward(self, L, ctx, tag, raw, count, garena, g1, act1, g2=None, act2=K.ACT_NONE, param_grads=True):
         f32 = torch.float32
         c = L.cout
@@ -416,9 +451,7 @@ class GeneratorEngine(_Engine):
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws, c_real=sum(L.in_real))
                 K.bn_act(raw, None, None, aL, aR)
             else:
-                st = K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
-                scale, shift = self._bn_coeffs(L, ctx, f"e{k}", st, B * h * w, train, bn_repeats)
-                K.bn_act(raw, scale, shift, aL, aR)
+                self._conv_bn_act(K.CONV_S2, [a], L, ctx, f"e{k}", raw, (B, h, w), train, bn_repeats, aL, aR)
             ctx.v["aL"][k], ctx.v["aR"][k] = aL, aR
             a = aL
         for k in range(D - 1, 0, -1):
@@ -432,10 +465,8 @@ class GeneratorEngine(_Engine):
                 ctx.v["uR"][k] = uR
                 continue
             raw = ctx.buf(f"u{k}.raw", (B, 2 * h, 2 * w, L.cout_p), dt)
-            st = K.gather_gemm(K.TCONV_S2, srcs, L.w_fwd, L.cout, [raw], (B, h, w), self.ws, stats=train)
-            scale, shift = self._bn_coeffs(L, ctx, f"u{k}", st, B * 4 * h * w, train, bn_repeats)
             uR = ctx.buf(f"u{k}.uR", raw.shape, dt)
-            K.bn_act(raw, scale, shift, None, uR)
+            self._conv_bn_act(K.TCONV_S2, srcs, L, ctx, f"u{k}", raw, (B, h, w), train, bn_repeats, None, uR)
             ctx.v["uR"][k] = uR
         L = self.up[0]
         fake = ctx.buf("fake", (B, H, W, L.cout_p), dt)
@@ -495,9 +526,8 @@ class GeneratorEngine(_Engine):
                 Ln = self.down[k]
                 if fusable:
                     dr = ctx.buf(f"e{k}.dy", srcs[0].shape, dt)
-                    K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [dr], (B, h, w), self.ws,
-                                  fuse=self._fuse_spec(Ln, ctx, f"e{k}", 1, v["aR"][k], K.ACT_RELU))
-                    ready[f"e{k}"] = dr
+                    ready[f"e{k}"] = self._dgrad_fused(K.CONV_S2, d, L.w_bwd, L.conv.in_channels, [dr], (B, h, w), Ln, ctx,
+                                                       f"e{k}", 1, v["aR"][k], K.ACT_RELU, garena)
                 else:
                     g_skip[k] = ctx.buf(f"g.skip{k}", srcs[0].shape, dt)
                     K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k]], (B, h, w), self.ws)
@@ -507,9 +537,8 @@ class GeneratorEngine(_Engine):
             if fusable:
                 dyn = ctx.buf(f"u{k + 1}.dy", srcs[1].shape, dt)
                 rawn = ctx.buf(f"u{k + 1}.raw", srcs[1].shape, dt)
-                st = K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], dyn], (B, h, w), self.ws,
-                                   fuse=self._fuse_spec(Ln, ctx, f"u{k + 1}", 2, rawn, K.ACT_RELU))
-                ready[f"u{k + 1}"] = self._finish_fused(Ln, ctx, f"u{k + 1}", rawn, B * h * w, garena, dyn, st)
+                ready[f"u{k + 1}"] = self._dgrad_fused(K.CONV_S2, d, L.w_bwd, L.conv.in_channels, [g_skip[k], dyn], (B, h, w),
+                                                       Ln, ctx, f"u{k + 1}", 2, rawn, K.ACT_RELU, garena)
             else:
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
                 K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], g_up[k + 1]], (B, h, w), self.ws)
@@ -544,10 +573,8 @@ class GeneratorEngine(_Engine):
                 if K.fuse_ok(K.TCONV_S2, [dr], src.shape[3], (B, h, w), single_ld=src.shape[3]):
                     rawp = ctx.buf(f"e{k - 1}.raw", src.shape, dt) if Lp.bn is not None else v["aL"][k - 1]
                     dyp = ctx.buf(f"e{k - 1}.dy", src.shape, dt)
-                    st = K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [dyp], (B, h, w), self.ws,
-                                       fuse=self._fuse_spec(Lp, ctx, f"e{k - 1}", 1, rawp, K.ACT_LRELU, g_skip[k - 1],
-                                                            K.ACT_RELU))
-                    ready[f"e{k - 1}"] = self._finish_fused(Lp, ctx, f"e{k - 1}", rawp, B * hp * wp, garena, dyp, st)
+                    ready[f"e{k - 1}"] = self._dgrad_fused(K.TCONV_S2, dr, L.w_bwd, src.shape[3], [dyp], (B, h, w), Lp, ctx,
+                                                           f"e{k - 1}", 1, rawp, K.ACT_LRELU, garena, g_skip[k - 1], K.ACT_RELU)
                 else:
                     g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                     K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)

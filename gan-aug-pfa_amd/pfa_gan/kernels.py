@@ -154,8 +154,25 @@ def fuse_ok(mode, srcs, n, grid, single_ld=None):
     return n % 4 == 0 and n // 4 <= 256 and 256 % (n // 4) == 0 and (single_ld is None or single_ld == n)
 
 
+# Whole-batch finish of the small K-sliced layers: rows up to which it is taken (0 = never).  One workgroup per 16 columns
+# means n / 16 = 32 workgroups read the whole slab: measured against finish pass + bn_finalize + bn_act it wins at 256 rows
+# (4x4 maps at B = 16: 8.9 / 14.5 us against 15.7 / 18.9) and loses from 1024 rows on (43 us against 21: the 33 MB slab of a
+# 16-slice launch needs the whole chip's bandwidth).
+FINISH_BN_ROWS = int(_os.environ.get("PFA_FINISH_BN_ROWS", "256"))
+
+
+def defer_ok(mode, srcs, n, grid, rows):
+    """Will this launch be K-sliced on the implicit GEMM (a map too small for the patch kernels) with few enough rows that
+    one workgroup can finish a column group over the whole batch (finish_bn_fwd / finish_bn_bwd)?"""
+    if rows > FINISH_BN_ROWS or srcs[0].dtype != torch.bfloat16 or (grid[1] >= 8 and grid[2] >= 16):
+        return False
+    if not lib().pfa_finish_bn_supported(dt_code(srcs[0].dtype), rows, n):
+        return False
+    return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(t.shape[3] for t in srcs), srcs[0].dtype) > 1
+
+
 def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats=False, splitk=None, fuse=None,
-                affine=None, c_real=0):
+                affine=None, c_real=0, defer=False):
     """out = act(bias + implicit_gemm(srcs, w)).  srcs/outs: lists of 1 or 2 NHWC tensors.
 
     grid = (nb, hq, wq) position grid.  Returns (psum, psq, ntiles) views when stats=True.
@@ -165,6 +182,8 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     affine: (scale, shift, act2) - eval-mode BatchNorm in the epilogue: outs[0] = act(scale*acc + shift) and, with two
     outs, outs[1] = act2(scale*acc + shift) over the same columns (needs splitk == 1: check auto_splitk first).
     c_real: real (unpadded) contraction channels, for the FLOP accounting of pfa_gather_timing only (0 = as padded).
+    defer: run the K slices only (defer_ok must hold) and return (slab, planes): the caller finishes them with
+    finish_bn_fwd / finish_bn_bwd; `outs` then only give the output geometry.
     """
     _require_cuda(*srcs, w, *outs)
     dtype = srcs[0].dtype
@@ -187,8 +206,14 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     a.w, a.bias = ptr(w), ptr(bias)
     a.out1, a.out2 = ptr(outs[0]), ptr(outs[1]) if len(outs) > 1 else None
     npix = outs[0].shape[0] * outs[0].shape[1] * outs[0].shape[2]
+    slab = None
     if a.splitk > 1:
-        a.slab = ptr(ws.get("slab", lib().pfa_gather_slab_floats(ctypes.byref(a))))
+        slab = ws.get("slab", lib().pfa_gather_slab_floats(ctypes.byref(a)))
+        a.slab = ptr(slab)
+    if defer:
+        a.fuse_out = _lib.FUSE_DEFER
+        check(lib().pfa_gather_gemm(ctypes.byref(a), stream()), "pfa_gather_gemm")
+        return slab, a.splitk
     psum = psq = None
     if affine is not None:
         a.fuse_out, a.fuse_act2 = 3, affine[2]
@@ -287,6 +312,31 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None):
         # (and are reproducible); with a few slices over a large dw the atomics are as fast and need no workspace
         a.slab = ptr((ws if ws is not FORCE_SLAB else _FORCE_WS).get("wgslab", lib().pfa_wgrad_slab_floats(ctypes.byref(a))))
     check(lib().pfa_wgrad(ctypes.byref(a), stream()), "pfa_wgrad")
+
+
+# ------------------------------------------------------------------------------- whole-batch finish of small layers
+def finish_bn_fwd(slab, planes, n, bn, repeats, raw, out_l, out_r, scale, shift, mean, invstd):
+    """K-slice combine + BatchNorm2d training forward + LeakyReLU / ReLU outputs in one launch (see pfa_hip.h)."""
+    rows = rows_of(raw)
+    track = bn.track_running_stats and bn.running_mean is not None
+    check(lib().pfa_finish_bn_fwd(ptr(slab), planes, rows, n, ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
+                                  repeats if track else 0,
+                                  ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                  ptr(bn.num_batches_tracked) if track else None, dt_code(raw.dtype), ptr(raw), raw.shape[3],
+                                  ptr(out_l), ptr(out_r), SLOPE, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream()),
+          "pfa_finish_bn_fwd")
+
+
+def finish_bn_bwd(slab, planes, n, plain, fuse, gamma, dgamma, dbeta, dr):
+    """K-slice combine + the fused backward of gather_gemm(fuse=...) + bn_bwd_finalize + bn_bwd_apply in one launch.
+    plain: the first output of a two-output launch (columns [0, n1)) or None; dr: the fused output."""
+    rows = rows_of(dr)
+    n1 = plain.shape[3] if plain is not None else 0
+    check(lib().pfa_finish_bn_bwd(ptr(slab), planes, rows, n, n1, ptr(plain), n1, ptr(fuse["raw"]), ptr(fuse.get("g2")),
+                                  fuse["act1"], fuse.get("act2", ACT_NONE), SLOPE, ptr(fuse.get("scale")),
+                                  ptr(fuse.get("shift")), ptr(fuse.get("mean")), ptr(fuse.get("invstd")), ptr(gamma),
+                                  ptr(dgamma), ptr(dbeta), dt_code(dr.dtype), ptr(dr), dr.shape[3], stream()),
+          "pfa_finish_bn_bwd")
 
 
 # ------------------------------------------------------------------------------- the PatchGAN logit layer

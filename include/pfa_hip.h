@@ -125,7 +125,7 @@ typedef struct pfa_gather_args {
      * receives dy = act1'(y)*g + act2'(y)*g2 instead of g, with y = scale*raw + shift (scale NULL: y = raw) and raw the
      * conv output that output is the gradient of (same shape).  With mean/invstd, psum/psq receive the per-tile
      * sums of dy and dy*xhat over the fused output's columns (row length = its ld) for pfa_bn_bwd_finalize. */
-    int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2, 3 = affine epilogue (below)      */
+    int32_t fuse_out;            /* 0 = off, 1 = out1, 2 = out2, 3 = affine epilogue (below), 4 = PFA_FUSE_DEFER */
     int32_t fuse_act1, fuse_act2;
     int32_t c_real;              /* real (unpadded) contraction channels of src1|src2 for the FLOP accounting of      */
                                  /* pfa_gather_timing only; 0 = c1 + c2.  Never changes a result.                     */
@@ -313,6 +313,28 @@ int pfa_unpack_u8(const void* src, int64_t pixels, int c, int cp, int dtype, flo
 int pfa_fill_zero(void* p, size_t bytes, pfa_stream s);
 /* y[i] += alpha * x[i], float32 (loss bookkeeping of train_gan.py:63,71,74-75 kept on the device). */
 int pfa_axpy(float* y, const float* x, int64_t n, float alpha, pfa_stream s);
+
+/* ------------------------------------------------------------------ whole-batch finish of small K-sliced layers
+ * pfa_gather_gemm with fuse_out = PFA_FUSE_DEFER runs the K slices only and leaves the float32 partial planes
+ * [splitk][rows][n] in the slab (rows = output pixels; on return a->splitk holds the number of planes written).  For layers
+ * with at most 4096 rows and n %% 16 == 0 (pfa_finish_bn_supported) the two entry points below then finish them in ONE
+ * launch in which a workgroup owns all rows of a 16-column group:
+ *   _fwd  conv output (bf16 `raw`) + BatchNorm2d training forward (nn.BatchNorm2d of models.py:179,181: batch statistics,
+ *         running buffers updated `repeats` times, scale/shift/mean/invstd for the backward) + LeakyReLU -> out_l and/or
+ *         ReLU -> out_r: replaces the finish pass + pfa_bn_finalize + pfa_bn_act.
+ *   _bwd  input-gradient finish + the backward of the node the gradient belongs to, as fuse_out 1|2 + pfa_bn_bwd_finalize +
+ *         pfa_bn_bwd_apply compute it: columns [0, n1) are a plain sum -> `plain`; columns [n1, n): d = act1'(y) g +
+ *         act2'(y) g2 (y = scale raw + shift), and with mean / invstd the BatchNorm backward of d (dgamma / dbeta += ) -> dr. */
+#define PFA_FUSE_DEFER 4
+int pfa_finish_bn_supported(int dtype, int rows, int n);
+int pfa_finish_bn_fwd(const float* slab, int splitk, int rows, int n, const float* gamma, const float* beta, float eps,
+                      float momentum, int repeats, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      int dtype, void* raw, int ld, void* out_l, void* out_r, float slope, float* scale, float* shift,
+                      float* mean, float* invstd, pfa_stream s);
+int pfa_finish_bn_bwd(const float* slab, int splitk, int rows, int n, int n1, void* plain, int ld1, const void* raw,
+                      const void* g2, int act1, int act2, float slope, const float* scale, const float* shift,
+                      const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, int dtype,
+                      void* dr, int ld2, pfa_stream s);
 
 /* ------------------------------------------------------------------ launch lists
  * A training step is ~210 launches on three streams with the same arguments every iteration (static shapes, persistent

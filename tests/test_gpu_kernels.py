@@ -918,6 +918,153 @@ def test_batchnorm_roundtrip(dtype, ws):
     close(from_nhwc(out_l, c), ops.leaky_relu(ops.bn_eval_fwd(x, g, b, rm2, rv2)), dtype, "eval bn+lrelu")
 
 
+FINISH_BN_CASES = [  # name, mode, N, cin parts, H, W (input), Co
+    ("e5_like", "conv", 4, [64], 16, 16, 64),            # 8x8 maps: 256 rows, registers keep the slice sums
+    ("e6_ragged", "conv", 3, [128], 6, 10, 32),          # 3x5 maps: 45 rows, two column groups
+    ("d6_like", "tconv", 2, [64, 64], 4, 4, 64),         # transposed: 4 parity classes, two sources, 128 rows
+    ("d5_rows", "tconv", 16, [256], 7, 7, 32),           # 16 x 14 x 14 = 3136 rows: the variant that sums the slices twice
+]
+
+
+@pytest.mark.parametrize("case", FINISH_BN_CASES, ids=[c[0] for c in FINISH_BN_CASES])
+def test_whole_batch_finish_forward(case, ws):
+    """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_bn_fwd: K-slice combine, BatchNorm training forward (statistics, running
+    buffers x2, coefficients for the backward) and both activations in one launch - against the oracle's conv + BatchNorm,
+    and against the three-launch route (finish pass, bn_finalize, bn_act)."""
+    name, kind, n, cins, h, w, co = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".bx", (n, ci, h, w)), dtype)
+    if kind == "conv":
+        wt = rnd(fill.uniform(name + ".bw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        raw = ops.conv2d_fwd(x, wt, None, 2)
+        mode, grid = K.CONV_S2, (n, h // 2, w // 2)
+        wsh, _ = shadows(wt, dtype, cparts=[(c, c) for c in cins], want=("same",))
+    else:
+        wt = rnd(fill.uniform(name + ".bw", (ci, co, 4, 4), -0.25, 0.25), dtype)
+        raw = ops.convT2d_fwd(x, wt, None)
+        mode, grid = K.TCONV_S2, (n, h, w)
+        _, wsh = shadows(wt, dtype, want=("tr",))
+    ho, wo = raw.shape[2:]
+    rows = n * ho * wo
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    assert K.defer_ok(mode, srcs, co, grid, rows) == (rows <= K.FINISH_BN_ROWS)      # the engine's threshold; the kernels take more
+    assert _lib.lib().pfa_finish_bn_supported(K.dt_code(dtype), rows, co)
+    bn = torch.nn.BatchNorm2d(co).cuda()
+    g, b = fill.uniform(name + ".bg", (co,), 0.5, 1.5), fill.uniform(name + ".bb", (co,), -0.5, 0.5)
+    rm0, rv0 = fill.uniform(name + ".brm", (co,)), fill.uniform(name + ".brv", (co,), 0.5, 2.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(dev(g)); bn.bias.copy_(dev(b)); bn.running_mean.copy_(dev(rm0)); bn.running_var.copy_(dev(rv0))
+        bn.num_batches_tracked.fill_(5)
+    raw_r = rnd(raw, dtype)                                             # the stored conv output is what is normalised
+    y, cache, rm2, rv2, nbt2 = ops.bn_train_fwd(raw_r, g, b, rm0, rv0, 5, repeats=2)
+    _, cache_x, rm_x, rv_x, _ = ops.bn_train_fwd(raw, g, b, rm0, rv0, 5, repeats=2)   # statistics come from the float32 sums
+    shape = (n, ho, wo, co)
+    t_raw, t_l, t_r = (torch.full(shape, 7.0, dtype=dtype, device="cuda") for _ in range(3))
+    scale, shift, mean, invstd = (torch.empty(co, device="cuda") for _ in range(4))
+    before = _lib.launch_count()
+    slab, planes = K.gather_gemm(mode, srcs, wsh, co, [t_raw], grid, ws, defer=True)
+    assert planes > 1
+    K.finish_bn_fwd(slab, planes, co, bn, 2, t_raw, t_l, t_r, scale, shift, mean, invstd)
+    assert _lib.launch_count() - before == 2
+    torch.cuda.synchronize()
+    amax = np.abs(raw).max()
+    close(from_nhwc(t_raw, co), raw, dtype, name + ".raw", scale=amax)
+    close(mean.cpu().numpy(), raw.astype(np.float64).mean(axis=(0, 2, 3)), torch.float32, name + ".mean", scale=amax)
+    close(invstd.cpu().numpy(), cache_x[1], torch.float32, name + ".invstd")
+    close(bn.running_mean.cpu().numpy(), rm_x, torch.float32, name + ".running_mean")
+    close(bn.running_var.cpu().numpy(), rv_x, torch.float32, name + ".running_var")
+    assert int(bn.num_batches_tracked) == nbt2 == 7
+    # normalised outputs: the oracle on the ROUNDED conv output with the statistics of the unrounded one
+    inv = cache_x[1].astype(np.float64)
+    mu = raw.astype(np.float64).mean(axis=(0, 2, 3))
+    yy = ((raw_r - mu[None, :, None, None]) * (inv * g)[None, :, None, None] + b[None, :, None, None]).astype(np.float32)
+    close(from_nhwc(t_l, co), ops.leaky_relu(yy), dtype, name + ".lrelu", scale=np.abs(yy).max())
+    close(from_nhwc(t_r, co), ops.relu(yy), dtype, name + ".relu", scale=np.abs(yy).max())
+    # the three-launch route on the same inputs
+    with torch.no_grad():
+        bn.running_mean.copy_(dev(rm0)); bn.running_var.copy_(dev(rv0)); bn.num_batches_tracked.fill_(5)
+    u_raw, u_l, u_r = (torch.empty(shape, dtype=dtype, device="cuda") for _ in range(3))
+    st = K.gather_gemm(mode, srcs, wsh, co, [u_raw], grid, ws, stats=True)
+    sc2, sh2, mu2, is2 = (torch.empty(co, device="cuda") for _ in range(4))
+    K.bn_finalize(st[0], st[1], st[2], co, rows, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                  sc2, sh2, mu2, is2, repeats=2)
+    K.bn_act(u_raw, sc2, sh2, u_l, u_r)
+    torch.cuda.synchronize()
+    assert torch.equal(u_raw, t_raw)                                     # same slices, same ascending combine
+    close(scale.cpu().numpy(), sc2.cpu().numpy(), torch.float32, name + ".scale vs 3 launches")
+    close(shift.cpu().numpy(), sh2.cpu().numpy(), torch.float32, name + ".shift vs 3 launches", scale=np.abs(sh2.cpu().numpy()).max() + 1)
+    close(from_nhwc(t_l, co), from_nhwc(u_l, co), dtype, name + ".lrelu vs 3 launches", scale=np.abs(yy).max())
+
+
+FINISH_BWD_CASES = [  # name, N, cin, H, W, Co, BatchNorm, second gradient, two outputs
+    ("bn", 2, [64], 8, 8, 64, True, False, False),
+    ("bn_g2", 3, [128], 6, 10, 32, True, True, False),
+    ("act_only", 2, [64], 8, 8, 32, False, False, False),            # the innermost level: ReLU' only
+    ("two_outputs", 2, [64], 8, 8, 64, True, False, True),           # [plain 32 | fused 32]: the decoder's input gradient
+    ("many_rows", 16, [64], 28, 28, 16, True, True, False),          # 3136 rows
+]
+
+
+@pytest.mark.parametrize("case", FINISH_BWD_CASES, ids=[c[0] for c in FINISH_BWD_CASES])
+def test_whole_batch_finish_backward(case, ws):
+    """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_bn_bwd: K-slice combine, dy = LeakyReLU'(y) g (+ ReLU'(y) g2) and the
+    BatchNorm backward of dy (dgamma, dbeta accumulated) in one launch, against the oracle."""
+    name, n, cins, h, w, co, bn, with_g2, two = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".wx", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".ww", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    g = ops.conv2d_fwd(x, wt, None, 2)                                  # [n, co, ho, wo]: the incoming gradient
+    ho, wo = g.shape[2:]
+    rows = n * ho * wo
+    wsh, _ = shadows(wt, dtype, want=("same",))
+    srcs = [to_nhwc(x, dtype)]
+    assert K.defer_ok(K.CONV_S2, srcs, co, (n, ho, wo), rows) == (rows <= K.FINISH_BN_ROWS)
+    c0 = co // 2 if two else 0
+    cf = co - c0
+    raw = rnd(fill.uniform(name + ".wraw", (n, cf, ho, wo), -1.0, 1.0), dtype)
+    g2 = rnd(fill.uniform(name + ".wg2", (n, cf, ho, wo), -1.0, 1.0), dtype) if with_g2 else None
+    gam = fill.uniform(name + ".wgam", (cf,), 0.5, 1.5)
+    bet = fill.uniform(name + ".wbet", (cf,), -0.3, 0.3)
+    if bn:
+        y, cache, _, _, _ = ops.bn_train_fwd(raw, gam, bet, np.zeros(cf, np.float32), np.ones(cf, np.float32), 0)
+        mean = raw.astype(np.float64).mean(axis=(0, 2, 3)).astype(np.float32)
+        invstd = cache[1]
+        scale, shift = (gam * invstd).astype(np.float32), (bet - mean * gam * invstd).astype(np.float32)
+    else:
+        y = raw
+    gf = g[:, c0:]
+    d = np.where(y > 0, 1.0, 0.2) * gf + ((y > 0) * g2 if with_g2 else 0.0)
+    if bn:
+        want, dg_ref, db_ref = ops.bn_train_bwd(d.astype(np.float32), gam, cache)
+    else:
+        want = d
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    spec = dict(raw=to_nhwc(raw, dtype), act1=K.ACT_LRELU, g2=to_nhwc(g2, dtype) if with_g2 else None,
+                act2=K.ACT_RELU if with_g2 else K.ACT_NONE)
+    if bn:
+        spec.update(scale=dev(scale), shift=dev(shift), mean=dev(mean), invstd=dev(invstd))
+    plain = torch.full((n, ho, wo, c0), 7.0, dtype=dtype, device="cuda") if two else None
+    dr = torch.full((n, ho, wo, cf), 7.0, dtype=dtype, device="cuda")
+    dgamma, dbeta = torch.full((cf,), 0.5, device="cuda"), torch.full((cf,), 0.25, device="cuda")
+    before = _lib.launch_count()
+    slab, planes = K.gather_gemm(K.CONV_S2, srcs, wsh, co, [plain, dr] if two else [dr], (n, ho, wo), ws, defer=True)
+    K.finish_bn_bwd(slab, planes, co, plain, spec, dev(gam) if bn else None, dgamma if bn else None, dbeta if bn else None, dr)
+    assert _lib.launch_count() - before == 2 and planes > 1
+    torch.cuda.synchronize()
+    close(from_nhwc(dr, cf), want, dtype, name + ".dr", scale=np.abs(want).max())
+    if two:
+        close(from_nhwc(plain, c0), g[:, :c0], dtype, name + ".plain", scale=np.abs(g).max())
+    if bn:
+        close((dgamma - 0.5).cpu().numpy(), dg_ref, dtype, name + ".dgamma", scale=np.abs(dg_ref).max())
+        close((dbeta - 0.25).cpu().numpy(), db_ref, dtype, name + ".dbeta", scale=np.abs(db_ref).max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
 def test_losses(dtype, ws):
     x = rnd(fill.uniform("gl.x", (3, 1, 6, 5), -4, 4), dtype)
