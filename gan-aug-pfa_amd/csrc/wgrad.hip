@@ -40,6 +40,7 @@ struct WgradK {
     float* slab;     // optional [msplit][tiles][BI*128] partial tiles (deterministic combine instead of atomics)
     int kgroups;     // 1, or 2: K-group pairs (k_wgrad KG)
     int msplit;
+    int fresh;       // dw holds zeros and this launch has one slice: store, do not add
 };
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
@@ -362,7 +363,10 @@ __global__ __launch_bounds__(64 * WI * WJ * KG) __attribute__((amdgpu_waves_per_
                 int ireal;
                 if (ip < p.d1p) ireal = ip < p.d1r ? ip : -1;
                 else ireal = (ip - p.d1p) < p.d2r ? p.d1r + ip - p.d1p : -1;
-                if (ireal >= 0) atomicAdd(p.dw + ((size_t)ireal * 16 + tap) * p.gr + creal, acc[a][b][r]);
+                if (ireal < 0) continue;
+                float* q = p.dw + ((size_t)ireal * 16 + tap) * p.gr + creal;
+                if (p.fresh && p.msplit == 1) *q = acc[a][b][r];        // one slice: this workgroup is the only writer
+                else atomicAdd(q, acc[a][b][r]);
             }
         }
     }
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
     for (int u = 0; k < k1; ++k, ++u, src += stride) s[u] += *src;
     const float tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     float* dst = p.dw + ((size_t)ireal * 16 + tap) * p.gr + creal;
-    if (gridDim.y == 1) *dst += tot;
+    if (gridDim.y == 1) *dst = p.fresh ? tot : *dst + tot;
     else atomicAdd(dst, tot);
 }
 
@@ -457,6 +461,7 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     k.dir1 = (const char*)a->dir1; k.dir2 = (const char*)a->dir2;
     k.gat1 = (const char*)a->gat1; k.gat2 = (const char*)a->gat2; k.dw = a->dw;
     k.slab = a->slab;
+    k.fresh = a->fresh;
     k.stride = a->stride; k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hg = a->hg; k.wg = a->wg;
     k.d1p = a->d1p; k.d1r = a->d1r; k.d2p = a->d2p; k.d2r = a->d2r; k.dp = a->d1p + a->d2p;
     k.g1p = a->g1p; k.g1r = a->g1r; k.g2p = a->g2p; k.g2r = a->g2r; k.gp = a->g1p + a->g2p; k.gr = a->g1r + a->g2r;

@@ -37,6 +37,7 @@ struct WgpK {
     int d1p, dp, gp;         // direct channels of source 1 / in all, gathered channels
     int nb, hq, wq, hg, wg;
     int tiles_x, tiles_y, nsteps, sper, msplit;
+    int fresh;               // pfa_wgrad_args.fresh
     int itiles, ctiles, nwg;
 };
 
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const WgpK p) {
     const float* src = p.slab + e;
     for (int k = 0; k < p.msplit; ++k) s += *(const f32x4*)(src + (size_t)k * ntiles * per);
     float* dst = p.dw + ((size_t)(it * 128 + i) * 16 + ky * 4 + kx) * p.gp + ct * 64 + c;
-    *(f32x4*)dst = *(const f32x4*)dst + s;
+    if (p.fresh) *(f32x4*)dst = s;               // (dw holds zeros: no need to read it)
+    else *(f32x4*)dst = *(const f32x4*)dst + s;
 }
 
 template <int STRIDE, int TX>
@@ -362,7 +364,7 @@ int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name) 
     PFA_REQUIRE(pfa_wgrad_patch_plan(a, &ms, &tx, &steps), "pfa_wgrad_patch: geometry not supported");
     WgpK k;
     k.dir1 = (const char*)a->dir1; k.dir2 = (const char*)a->dir2; k.gat = (const char*)a->gat1;
-    k.dw = a->dw; k.slab = a->slab;
+    k.dw = a->dw; k.slab = a->slab; k.fresh = a->fresh;
     k.d1p = a->d1p; k.dp = a->d1p + a->d2p; k.gp = a->g1p;
     k.nb = a->nb; k.hq = a->hq; k.wq = a->wq; k.hg = a->hg; k.wg = a->wg;
     const int ty = 64 / tx;

@@ -36,7 +36,7 @@ class WgradArgs(Structure):
         ("nb", c_int32), ("hq", c_int32), ("wq", c_int32), ("hg", c_int32), ("wg", c_int32),
         ("d1p", c_int32), ("d1r", c_int32), ("d2p", c_int32), ("d2r", c_int32),
         ("g1p", c_int32), ("g1r", c_int32), ("g2p", c_int32), ("g2r", c_int32),
-        ("msplit", c_int32), ("reserved", c_int32),
+        ("msplit", c_int32), ("fresh", c_int32),
         ("dir1", c_void_p), ("dir2", c_void_p), ("gat1", c_void_p), ("gat2", c_void_p), ("dw", c_void_p),
         ("slab", c_void_p),
     ]

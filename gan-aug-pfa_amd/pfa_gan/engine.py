@@ -515,7 +515,7 @@ class GeneratorEngine(_Engine):
             srcs = [v["aR"][k]] if k == D - 1 else [v["aR"][k], v["uR"][k + 1]]
 
             def pg(ws, L=L, srcs=srcs, d=d):
-                K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=ws)
+                K.wgrad(srcs, [d], L.dw(garena), 2, L.in_real, [L.cout], ws=ws, fresh=True)
                 if L.b is not None:
                     K.colsum(d, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
@@ -563,7 +563,7 @@ class GeneratorEngine(_Engine):
             src = v["x"] if k == 0 else v["aL"][k - 1]
 
             def pg(ws, L=L, dr=dr, src=src):
-                K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=ws)
+                K.wgrad([dr], [src], L.dw(garena), 2, [L.cout], L.in_real, ws=ws, fresh=True)
                 if L.b is not None:
                     K.colsum(dr, L.db(garena), ws, c_out=L.cout)
             self._param_grads(side, pg)
@@ -653,21 +653,24 @@ class DiscriminatorEngine(_Engine):
         return (i == len(self.layers) - 1 and i > 0 and L.cout == 1 and L.stride == 1 and len(inputs) == 1
                 and K.logit_ok(inputs[0], L.cout_p))
 
-    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None):
+    def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None,
+                 fresh=True):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55).
         need_dx: return dL/d(input) [B,H,W,sum(in_pad)]; with dx_part=i only the gradient of input source i
-        ([B,H,W,in_pad[i]]) is computed - the G phase needs dL/dfake, not dL/dreal_A."""
+        ([B,H,W,in_pad[i]]) is computed - the G phase needs dL/dfake, not dL/dreal_A.
+        fresh: garena holds zeros where this pass writes weight gradients (False for a second pass that accumulates into the
+        arena of a first one)."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:
-            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part)
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh)
         finally:
             self.ws_cur = self.ws
 
-    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None):
+    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -695,7 +698,7 @@ class DiscriminatorEngine(_Engine):
                     if logit:
                         K.logit_wgrad(dr, inputs[0], L.dw(garena), L.db(garena) if L.b is not None else None)
                         return
-                    K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=ws)
+                    K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=ws, fresh=fresh)
                     if L.b is not None:
                         K.colsum(dr, L.db(garena), ws, c_out=L.cout)
                 self._param_grads(side, pg)

@@ -111,9 +111,9 @@ class _Conv4x4Fn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.zeros((rows, 16, c), dtype=torch.float32, device=dev)
             if transposed:          # master rows = input channels: the input is the direct operand, gy the gathered one
-                K.wgrad([xh], [gyh], dw, 2, [rows], [c], ws=ws)
+                K.wgrad([xh], [gyh], dw, 2, [rows], [c], ws=ws, fresh=True)
             else:
-                K.wgrad([gyh], [xh], dw, stride, [rows], [c], ws=ws)
+                K.wgrad([gyh], [xh], dw, stride, [rows], [c], ws=ws, fresh=True)
             gw = dw.reshape(rows, 4, 4, c).permute(0, 3, 1, 2).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             cout = c if transposed else rows

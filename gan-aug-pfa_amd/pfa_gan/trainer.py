@@ -199,7 +199,7 @@ class GanTrainer:
             dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
             K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
             Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
-            Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
+            Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, fresh=False)      # accumulates into the first pass's arena
             return
         # Three streams.  side: the whole D(real) forward + backward (it needs neither the generator nor D(fake)) into
         # the second gradient arena; main: G forward -> D(fake) forward -> D(fake) dgrad/BatchNorm chain; side2: D(fake)'s

@@ -163,7 +163,8 @@ typedef struct pfa_wgrad_args {
     int32_t d1p, d1r, d2p, d2r;  /* direct channels: padded / real, for src1 and src2 (d2*=0)  */
     int32_t g1p, g1r, g2p, g2r;  /* gathered channels likewise                                 */
     int32_t msplit;              /* number of slices of the reduction (>=1)                    */
-    int32_t reserved;
+    int32_t fresh;               /* nonzero: dw holds zeros (a fresh gradient buffer, written once): a launch with  */
+                                 /* ONE reduction slice then stores its tile instead of adding to it with atomics */
     const void* dir1;
     const void* dir2;
     const void* gat1;

@@ -735,6 +735,13 @@ def test_conv_wgrad(case, dtype, ws):
     K.wgrad([dyt], srcs, dw2, stride, [co], cins, msplit=msplit, ws=K.FORCE_SLAB)     # accumulates (zero_grad semantics)
     torch.cuda.synchronize()
     assert torch.equal(dw2, dw + dw), "slab combine must be bitwise reproducible and accumulate into dw"
+    # fresh=True: the caller vouches for a zeroed dw with one writer; launches that can (one slice; the slab reduce)
+    # store instead of adding - the same values
+    for use_ws in (None, K.FORCE_SLAB):
+        dw3 = torch.zeros_like(dw)
+        K.wgrad([dyt], srcs, dw3, stride, [co], cins, msplit=msplit, ws=use_ws, fresh=True)
+        torch.cuda.synchronize()
+        close(dw3.cpu().numpy().reshape(co, 4, 4, ci).transpose(0, 3, 1, 2), want, torch.float32, name + " fresh")
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)

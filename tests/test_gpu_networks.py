@@ -413,7 +413,10 @@ def test_bench_two_ranks_contract(spelling):
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
     assert out["value"] > 0 and abs(out["value"] - 4 * 3 / (out["ms_per_step"] * 3e-3)) < 0.02 * out["value"]
     assert len(out["repeats_ms_per_step"]) == 2
-    assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+    # (two processes time-slice ONE GPU here: a launch's event pair spans the other rank's slices, so the rate itself is
+    # meaningless in this test - the object, its kernel and its per-launch work are what the contract needs)
+    rf = out["roofline"]
+    assert rf["avg_launch_us"] > 0 and rf["flop_per_launch"] > 0 and rf["achieved"] >= 0 and "cpu_baseline" not in out
     assert any(k["kernel"].startswith("k_wgrad") for k in out["roofline"]["kernels"])
 
 

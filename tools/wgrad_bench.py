@@ -12,8 +12,12 @@ L = [("e1", (128,128,[64]), (256,256,[8]), 2, [64], [3]),
      ("e3/c3", (32,32,[256]), (64,64,[128]), 2, [256], [128]),
      ("e4", (16,16,[512]), (32,32,[256]), 2, [512], [256]),
      ("e5", (8,8,[512]), (16,16,[512]), 2, [512], [512]),
+     ("e6", (4,4,[512]), (8,8,[512]), 2, [512], [512]),
+     ("e7", (2,2,[512]), (4,4,[512]), 2, [512], [512]),
      ("c4", (31,31,[512]), (32,32,[256]), 1, [512], [256]),
      ("c5", (30,30,[8]), (31,31,[512]), 1, [1], [512]),
+     ("d7", (2,2,[512]), (4,4,[512]), 2, [512], [512]),
+     ("d6", (4,4,[512,512]), (8,8,[512]), 2, [512,512], [512]),
      ("d5", (8,8,[512,512]), (16,16,[512]), 2, [512,512], [512]),
      ("d4", (16,16,[512,512]), (32,32,[256]), 2, [512,512], [256]),
      ("d3", (32,32,[256,256]), (64,64,[128]), 2, [256,256], [128]),
@@ -40,7 +44,7 @@ for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in L:
 print("total", tot)
 # ablation on two layers
 from pfa_gan import _lib
-for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in [L[2], L[5]]:
+for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in [L[2], L[7]]:
     d=[T(B,dh,dw,c) for c in dcs]; g=[T(B,gh,gw,c) for c in gcs]
     dwt=torch.zeros(sum(dreal)*16*sum(greal), device='cuda')
     row=[]
