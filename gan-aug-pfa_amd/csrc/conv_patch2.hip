@@ -53,7 +53,7 @@ struct Patch2K {
     int tiles_y, tiles_x, ntiles, nwg;
     int nss, ssper;          // super-steps in all / per K slice
     int c1chunks;            // 64-channel chunks that come from src1
-    unsigned long long* stamps;   // developer timing (pfa_set_debug_buffer): 8 clock stamps per workgroup, or NULL
+    unsigned long long* stamps;   // developer timing (pfa_set_debug_buffer): 16 slots per workgroup (8 shader-clock stamps, 2 of the 100 MHz real-time counter), or NULL
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -100,9 +100,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int qy0 = ty * TY, qx0 = tx * TX, n0 = nt * BN;
     const char* zero = (const char*)g_pfa_zero_page;
     auto stamp = [&](int k) {          // shader clock at four points of the workgroup's life (a separate measurement, never a result)
-        if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+        if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
+    if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
 
     // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding
     int ppix[PPASS];             // source pixel * 8 + piece (MODE 1: of plane (0,0); plane (ey,ex) adds (ey*ws + ex) * 8)
@@ -346,23 +347,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         else opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
     };
     const size_t trow = (((size_t)img * q.tiles_y + ty) * q.tiles_x + tx) * (MODE == 0 ? 4 : 1) + cls;
-    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of, q.stamps ? q.stamps + (size_t)blockIdx.x * 8 : nullptr);
+    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of, q.stamps ? q.stamps + (size_t)blockIdx.x * 16 : nullptr);
     if (q.stamps) {
         stamp(6);
         __builtin_amdgcn_s_waitcnt(0);  // (stamps only: the stores have been issued AND accepted)
         stamp(7);
+        if (tid == 0) q.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
-template <int MODE, int BN, int TILE16>
+template <int MODE, int BN, int TILE16, int ABL = 0>
 int launch_patch2(const Patch2K& k, hipStream_t st) {
     constexpr int LDS = 2 * PATCH_BYTES + W_SLOTS * BN * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_conv_patch2<MODE, BN, TILE16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)k_conv_patch2<MODE, BN, TILE16, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_conv_patch2<MODE, BN, TILE16>), dim3(k.nwg), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL((k_conv_patch2<MODE, BN, TILE16, ABL>), dim3(k.nwg), dim3(512), LDS, st, k);
     PFA_LAUNCHED("k_conv_patch2");
     return 0;
 }
@@ -414,12 +416,23 @@ int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, co
     PFA_REQUIRE((q.nss + q.ssper - 1) / q.ssper == plan.splitk, "pfa_conv_patch2: empty K slice");
     q.c1chunks = k.c1 / 64;
     q.stamps = nullptr;
-    if (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 64) q.stamps = (unsigned long long*)g_pfa_dbgbuf;
+    if (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 128) q.stamps = (unsigned long long*)g_pfa_dbgbuf;
     const int sel = (k.mode == PFA_CONV_S2 ? 4 : 0) + (plan.bn == 64 ? 2 : 0) + (plan.tile16 ? 1 : 0);
     static const char* names[8] = {"k_conv_patch2<tconv,128,8x32>", "k_conv_patch2<tconv,128,16x16>", "k_conv_patch2<tconv,64,8x32>",
                                    "k_conv_patch2<tconv,64,16x16>", "k_conv_patch2<conv_s2,128,8x32>", "k_conv_patch2<conv_s2,128,16x16>",
                                    "k_conv_patch2<conv_s2,64,8x32>", "k_conv_patch2<conv_s2,64,16x16>"};
     if (kernel_name) *kernel_name = names[sel];
+    if (sel == 4 && pfa_knob(7) >= 11 && pfa_knob(7) <= 17) {      // developer ablations of the stride-2 128-channel kernel (results are wrong)
+        switch (pfa_knob(7) - 10) {
+            case 1: return launch_patch2<1, 128, 0, 1>(q, st);     // no MFMA
+            case 2: return launch_patch2<1, 128, 0, 2>(q, st);     // no fragment reads
+            case 3: return launch_patch2<1, 128, 0, 3>(q, st);
+            case 4: return launch_patch2<1, 128, 0, 4>(q, st);     // no DMA
+            case 5: return launch_patch2<1, 128, 0, 5>(q, st);
+            case 6: return launch_patch2<1, 128, 0, 6>(q, st);
+            default: return launch_patch2<1, 128, 0, 7>(q, st);    // barriers, waits and address arithmetic only
+        }
+    }
     switch (sel) {
         case 0: return launch_patch2<0, 128, 0>(q, st);
         case 1: return launch_patch2<0, 128, 1>(q, st);

@@ -22,7 +22,7 @@ L = [
  ("e3/c3 dgrad", K.TCONV_S2, (32, 32, [256]), 128, (32, 32)),
 ]
 lib = _lib.lib()
-buf = torch.zeros(8192 * 8, dtype=torch.int64, device='cuda')
+buf = torch.zeros(8192 * 16, dtype=torch.int64, device='cuda')
 print(f"{'layer':14s} {'wgs':>5s} {'event us':>9s} | median cycles: prologue    loop  to-LDS    rows shuffle  reduce   drain |   total")
 for name, mode, (h, w, cs), n, (hq, wq) in L:
     srcs = [T(B, h, w, c) for c in cs]
@@ -40,7 +40,7 @@ for name, mode, (h, w, cs), n, (hq, wq) in L:
     K.gather_gemm(mode, srcs, wgt, n, [o], (B, hq, wq), ws, stats=stats)
     e1.record(); torch.cuda.synchronize()
     lib.pfa_set_debug_buffer(None, 0)
-    st = buf.view(-1, 8).cpu()
+    st = buf.view(-1, 16).cpu()
     st = st[st[:, 7] != 0]
     d = st.double()
     seg = [(d[:, k + 1] - d[:, k]) for k in range(7)]
@@ -48,4 +48,10 @@ for name, mode, (h, w, cs), n, (hq, wq) in L:
         seg[4] = d[:, 6] - d[:, 4]; seg[5] = seg[4] * 0
     med = [float(x.median()) for x in seg]
     tot = float((d[:, 7] - d[:, 0]).median())
-    print(f"{name:14s} {st.shape[0]:5d} {e0.elapsed_time(e1)*1e3:9.1f} | " + " ".join(f"{m:7.0f}" for m in med) + f" | {tot:7.0f}")
+    rt0, rt1 = d[:, 8], d[:, 9]                   # 100 MHz real-time counter: one time base for the whole chip
+    span = float(rt1.max() - rt0.min()) / 100.0
+    first = float((rt0 - rt0.min()).median()) / 100.0
+    life = float((rt1 - rt0).median()) / 100.0
+    mhz = tot / max(life, 1e-9)
+    print(f"{name:14s} {st.shape[0]:5d} {e0.elapsed_time(e1)*1e3:9.1f} | " + " ".join(f"{m:7.0f}" for m in med) + f" | {tot:7.0f} | "
+          f"first start -> last end {span:6.1f} us, median start offset {first:5.1f} us, median life {life:5.1f} us ({mhz:5.0f} MHz)")
