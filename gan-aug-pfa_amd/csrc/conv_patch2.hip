@@ -397,13 +397,16 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
         while (sk > 2 && tiles * (k.n / 64) * (sk / 2) >= want) sk /= 2;     // no more slices than the chip needs
         pl.splitk = sk;
     }
-    if (pfa_knob(3) != 2 && tiles * (k.n / pl.bn) * pl.splitk < 96) return false;      // too small to be worth a patch launch
+    if (pfa_knob(3) != 2 && pfa_knob(3) != 5 && tiles * (k.n / pl.bn) * pl.splitk < 96) return false;      // too small to be worth a patch launch
     pl.stat_tiles = (int)tiles;
+    // a transposed conv on 64-channel tiles is DMA-bound with one class per workgroup: all four classes over one patch
+    pl.tconv4 = (k.mode == PFA_TCONV_S2 && pl.bn == 64 && !pl.tile16 && pl.splitk == 1 && pfa_tconv4_ok(k, dtype, pl.tiles_y, pl.tiles_x)) ? 1 : 0;
     if (plan) *plan = pl;
     return true;
 }
 
 int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, const char** kernel_name) {
+    if (plan.tconv4) return pfa_tconv4(k, plan.tiles_y, plan.tiles_x, st, kernel_name);
     Patch2K q;
     q.g = k;
     q.g.splitk = plan.splitk;

@@ -48,7 +48,10 @@ struct Patch2Plan {
     int splitk;              // K slices actually used (<= the caller's)
     int tiles_y, tiles_x;    // position tiles per image
     int stat_tiles;          // rows of psum / psq an un-split launch writes
+    int tconv4;              // 1: the four parity classes of a transposed conv in one workgroup (csrc/conv_tconv4.hip)
 };
+bool pfa_tconv4_ok(const GatherK& k, int dtype, int tiles_y, int tiles_x);
+int pfa_tconv4(const GatherK& k, int tiles_y, int tiles_x, hipStream_t st, const char** kernel_name);
 bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan);
 int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, const char** kernel_name);
 

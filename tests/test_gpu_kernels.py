@@ -236,6 +236,10 @@ PATCH2_CASES = [  # name, kind, N, cin parts, H, W (input), Co, K slices, knob 6
     ("tconv_17", "tconv", 1, [64], 17, 20, 128, 1, 1, "k_conv_patch2<tconv,128,16x16>", None),         # ragged 16x16 tiles
     ("tconv_sliced", "tconv", 2, [128, 64], 16, 16, 64, 3, 0, "k_conv_patch2<tconv,64,16x16>", None),  # three K slices -> slab + finish
     ("tconv_wide", "tconv", 1, [64], 8, 70, 64, 1, 0, "k_conv_patch2<tconv,64,8x32>", None),           # three tile columns
+    # four parity classes per workgroup (conv_tconv4.hip; knob 3 = 5 takes it whatever the launch size)
+    ("t4_cat", "tconv", 2, [64, 64], 9, 33, 64, 1, 0, "k_tconv4<64,8x32>", None),                      # ragged tiles, two sources, 2 chunks
+    ("t4_two_ntiles", "tconv", 1, [64], 8, 40, 128, 1, 0, "k_tconv4<64,8x32>", None),                  # two 64-channel tiles, one chunk
+    ("t4_chunks3", "tconv", 1, [128, 64], 11, 32, 64, 1, 0, "k_tconv4<64,8x32>", None),                # an odd number of chunks
     ("conv_e2", "conv", 1, [64], 34, 70, 128, 1, 1, "k_conv_patch2<conv_s2,128,8x32>", None),          # out 17x35: ragged both ways
     ("conv_16", "conv", 2, [128], 32, 32, 192, 1, 0, "k_conv_patch2<conv_s2,64,16x16>", None),         # 3 n-tiles of 64
     ("conv_split_out", "conv", 2, [64], 32, 64, 128, 1, 1, "k_conv_patch2<conv_s2,128,8x32>", 64),    # two outputs (decoder dgrad)
@@ -270,7 +274,7 @@ def test_conv_patch2_kernels(case, ws):
         mode, grid = K.TCONV_S2, (n, h, w)
     lib = _lib.lib()
     res, stats = [], []
-    for knob3 in (2, 1):
+    for knob3 in (5 if kernel_want.startswith("k_tconv4") else 2, 1):
         shape = (n,) + want.shape[2:]
         outs = [torch.full(shape + (co,), 7.0, dtype=dtype, device="cuda")] if n1 is None else \
             [torch.full(shape + (n1,), 7.0, dtype=dtype, device="cuda"), torch.full(shape + (co - n1,), 7.0, dtype=dtype, device="cuda")]
@@ -282,7 +286,7 @@ def test_conv_patch2_kernels(case, ws):
         finally:
             lib.pfa_set_knob(3, 0)
             lib.pfa_set_knob(6, 0)
-        assert (kernel == kernel_want) if knob3 == 2 else kernel.startswith("k_gather_gemm"), kernel
+        assert (kernel == kernel_want) if knob3 != 1 else kernel.startswith("k_gather_gemm"), kernel
         got = from_nhwc(outs[0], outs[0].shape[3]) if n1 is None else \
             np.concatenate([from_nhwc(outs[0], n1), from_nhwc(outs[1], co - n1)], axis=1)
         res.append(got)
