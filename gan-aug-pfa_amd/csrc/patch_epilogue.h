@@ -192,36 +192,37 @@ __device__ __forceinline__ void patch_epilogue_rows(const GatherK& p, const int 
         rows(std::integral_constant<int, 0>{}, std::false_type{});
     }
 
-    // ---- partial statistics of this tile: lanes that share a chunk column inside a wave (lane % CPR), then the 8 waves
+    // ---- partial statistics of this tile.  Every thread holds the sums of its 8 channels over its rows; the 512 / CPR
+    // threads that share a chunk column meet through LDS: plain 16-byte writes, one barrier, then 2 BN threads add one column
+    // each (consecutive lanes, consecutive floats).  (Butterfly shuffles - 32-48 ds_bpermute with their waits - took 1.4-2 k
+    // cycles here, and the two-stage reduce behind them as much again.)
     if (stamps && tid == 0) stamps[4] = __builtin_amdgcn_s_memtime();       // (developer timing: rows issued)
     if (!stats) return;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int off = CPR; off < 64; off <<= 1) {
-            ss[e] += __shfl_xor(ss[e], off);
-            sq[e] += __shfl_xor(sq[e], off);
-        }
-    }
-    if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();       // (shuffles done)
+    constexpr int RG = 512 / CPR;                // row groups: threads per chunk column
     __syncthreads();                             // the fp32 image has been consumed
-    float* red = (float*)smem;                   // [8 waves][2][BN]
-    const int wave = tid >> 6;
-    if (lane < CPR) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[(wave * 2 + 0) * BN + lane * 8 + e] = ss[e];
-            red[(wave * 2 + 1) * BN + lane * 8 + e] = sq[e];
-        }
+    float* red = (float*)smem;                   // [RG][2][BN]
+    {
+        float* dst = red + (size_t)rsub * 2 * BN + cc * 8;
+        *(f32x4*)dst = f32x4{ss[0], ss[1], ss[2], ss[3]};
+        *(f32x4*)(dst + 4) = f32x4{ss[4], ss[5], ss[6], ss[7]};
+        *(f32x4*)(dst + BN) = f32x4{sq[0], sq[1], sq[2], sq[3]};
+        *(f32x4*)(dst + BN + 4) = f32x4{sq[4], sq[5], sq[6], sq[7]};
     }
+    if (stamps && tid == 0) stamps[5] = __builtin_amdgcn_s_memtime();
     __syncthreads();
-    const int scol = n0 + tid - p.stat_col0;
-    if (tid < BN && scol >= 0 && scol < p.stat_n) {
-        float s = 0.f, q = 0.f;
+    if (tid < 2 * BN) {
+        const int stat = tid / BN, c = tid - stat * BN;
+        const int scol = n0 + c - p.stat_col0;
+        const float* src = red + stat * BN + c;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) { s += red[(w * 2 + 0) * BN + tid]; q += red[(w * 2 + 1) * BN + tid]; }
-        p.psum[trow * p.stat_n + scol] = s;
-        p.psq[trow * p.stat_n + scol] = q;
+        for (int g = 0; g < RG; g += 4) {
+            t0 += src[(size_t)(g + 0) * 2 * BN];
+            t1 += src[(size_t)(g + 1) * 2 * BN];
+            t2 += src[(size_t)(g + 2) * 2 * BN];
+            t3 += src[(size_t)(g + 3) * 2 * BN];
+        }
+        if (scol >= 0 && scol < p.stat_n) (stat ? p.psq : p.psum)[trow * p.stat_n + scol] = (t0 + t1) + (t2 + t3);
     }
 }
 

@@ -42,6 +42,9 @@ for name, mode, (h, w, cs), n, (hq, wq) in L:
     lib.pfa_set_debug_buffer(None, 0)
     st = buf.view(-1, 16).cpu()
     st = st[st[:, 7] != 0]
+    if st.shape[0] == 0:
+        print(f"{name:14s} (no stamps: {lib.pfa_last_gather_kernel().decode()} does not write them)")
+        continue
     d = st.double()
     seg = [(d[:, k + 1] - d[:, k]) for k in range(7)]
     if not stats:       # stamps 5 is not written without statistics
