@@ -38,6 +38,7 @@ struct WgpK {
     int nb, hq, wq, hg, wg;
     int tiles_x, tiles_y, nsteps, sper, msplit;
     int fresh;               // pfa_wgrad_args.fresh
+    unsigned long long* stamps;   // developer timing (pfa_set_debug_buffer): 8 slots per workgroup, or NULL
     int itiles, ctiles, nwg;
 };
 
@@ -54,8 +55,10 @@ constexpr int NSTAGE = 4;
 constexpr int DIR_BYTES = 64 * 256;
 
 // STRIDE 1 | 2; TX 32 (2 x 32 positions per step) | 16 (4 x 16)
-template <int STRIDE, int TX>
+// ABL: ablation bits of a diagnostic instantiation (1 no MFMA, 2 no fragment reads, 4 no DMA - results are wrong)
+template <int STRIDE, int TX, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad_patch(const WgpK p) {
+    constexpr bool no_mfma = ABL & 1, no_read = ABL & 2, no_dma = ABL & 4;
     constexpr int TY = 64 / TX;
     constexpr int PLW = STRIDE == 1 ? TX + 3 : TX + 1;                    // pixels of a patch row (per plane at stride 2)
     constexpr int RP = ((STRIDE == 1 ? PLW : 2 * PLW) + 3) & ~3;          // row pitch in pixel slots, a multiple of 4
@@ -77,6 +80,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int split = wid / p.itiles;
     const int i0 = it * 128, c0 = ct * 64;
     const char* zero = (const char*)g_pfa_zero_page;
+    auto stamp = [&](int k) {          // shader clock at points of the workgroup's life (a separate measurement, never a result)
+        if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int step0 = split * p.sper;
     const int nlive = min(p.nsteps, step0 + p.sper) - step0;       // real steps of this slice
     const int nsteps = (nlive + 3) & ~3;                           // the loop runs whole groups of four: the (at most three) extra
@@ -127,6 +135,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         d_ty = rem / p.tiles_x; d_tx = rem - d_ty * p.tiles_x;
     }
     auto stage = [&](int slot, int op0, int op1) {           // DMA ops [op0, op1) of step ds into ring slot `slot`
+        if (no_dma) return;
         const int qy0 = d_ty * TY, qx0 = d_tx * TX;
         const bool live = ds < nlive;
         const unsigned emask = (d_tx == p.tiles_x - 1 ? 1u : 0u) | (d_ty == p.tiles_y - 1 ? 2u : 0u) | (d_tx == 0 ? 4u : 0u) |
@@ -145,6 +154,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 const bool ok = live && (f & (emask | 16u)) == 0;
                 const char* tb = p.gat + ((long long)(d_img * p.hg + STRIDE * qy0) * p.wg + STRIDE * qx0) * p.gp * 2;
                 const char* gp = ok ? tb + g_off[j] : zero;
+                // (every lane takes part: masking the lanes of slots no fragment reads - row padding, the tail of the last
+                // pass - out of the instruction made the step 5 % slower, the DMA is not priced per active lane)
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(sbase + DIR_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
             }
         }
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int e = 0; e < 2; ++e) { fa[s][t][e] = bf16x4{}; fb[s][t][e] = bf16x4{}; }
     auto read_kstep = [&](auto slot_, auto s_) {             // the 8 reads of k-step S of the stage in ring slot SL
+        if (no_read) return;
         constexpr int SL = decltype(slot_)::value, S = decltype(s_)::value, SET = S & 1;
         constexpr int ppix = TX == 32 ? (S >> 1) * RP + 16 * (S & 1) : S * RP;      // first pixel slot of the k-step's rows
 #pragma unroll
@@ -214,6 +226,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     __builtin_amdgcn_s_barrier();
     read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    stamp(1);
 
     // one step on ring slot SL; more: a step follows
     auto body = [&](int i, auto slot_, const bool more) {
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         auto kstep = [&](auto s_) {
             constexpr int S = decltype(s_)::value, SET = S & 1;
             // fragments of this k-step have landed: the reads issued after them are those of the next k-step (8), if any
-            if (S < 3 || more) wait_lgkm<8>(); else wait_lgkm<0>();
+            if (!no_read) { if (S < 3 || more) wait_lgkm<8>(); else wait_lgkm<0>(); }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -236,7 +249,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const bf16x8 bv = __builtin_shufflevector(fb[SET][b][0], fb[SET][b][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a][b], 0, 0, 0);
+                    if (!no_mfma) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a][b], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -261,6 +274,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         body(i + 3, std::integral_constant<int, 3>{}, i + 4 < nsteps);
     }
 
+    stamp(2);
     // ---- epilogue: lane holds D[i = 8 g + 4 lh' + r][c = lane & 31] of tile (a, b): rows = direct channels, columns = gathered
     const int col = lane & 31, rh = lane >> 5;
     const int tile = (it * 4 + ky) * p.ctiles + ct;
@@ -275,6 +289,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                     const int i = wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
                     dst[(i * 4 + kx) * 64 + b * 32 + col] = acc[a][b][e];
                 }
+        if (p.stamps) {
+            __builtin_amdgcn_s_waitcnt(0);
+            stamp(3);
+            if (tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        }
         return;
     }
 #pragma unroll
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const WgpK p) {
     else *(f32x4*)dst = *(const f32x4*)dst + s;
 }
 
-template <int STRIDE, int TX>
+template <int STRIDE, int TX, int ABL = 0>
 int launch_wgp(const WgpK& k, hipStream_t st) {
     constexpr int TY = 64 / TX;
     constexpr int PLW = STRIDE == 1 ? TX + 3 : TX + 1;
@@ -315,10 +334,10 @@ int launch_wgp(const WgpK& k, hipStream_t st) {
     constexpr int LDS = NSTAGE * (DIR_BYTES + PP * 8192);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad_patch<STRIDE, TX>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)k_wgrad_patch<STRIDE, TX, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_wgrad_patch<STRIDE, TX>), dim3(k.nwg), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL((k_wgrad_patch<STRIDE, TX, ABL>), dim3(k.nwg), dim3(512), LDS, st, k);
     PFA_LAUNCHED("k_wgrad_patch");
     return 0;
 }
@@ -372,7 +391,19 @@ int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name) 
     k.nsteps = steps; k.msplit = ms; k.sper = (steps + ms - 1) / ms;
     k.itiles = k.dp / 128; k.ctiles = k.gp / 64;
     k.nwg = k.itiles * 4 * k.ctiles * ms;
+    k.stamps = (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)k.nwg * 64) ? (unsigned long long*)g_pfa_dbgbuf : nullptr;
     int rc;
+    if (a->stride == 2 && tx == 32 && pfa_knob(7) >= 11 && pfa_knob(7) <= 17) {        // developer ablations (results are wrong)
+        switch (pfa_knob(7) - 10) {
+            case 1: rc = launch_wgp<2, 32, 1>(k, st); break;
+            case 2: rc = launch_wgp<2, 32, 2>(k, st); break;
+            case 3: rc = launch_wgp<2, 32, 3>(k, st); break;
+            case 4: rc = launch_wgp<2, 32, 4>(k, st); break;
+            case 5: rc = launch_wgp<2, 32, 5>(k, st); break;
+            case 6: rc = launch_wgp<2, 32, 6>(k, st); break;
+            default: rc = launch_wgp<2, 32, 7>(k, st); break;
+        }
+    } else
     if (a->stride == 1) rc = tx == 32 ? launch_wgp<1, 32>(k, st) : launch_wgp<1, 16>(k, st);
     else rc = tx == 32 ? launch_wgp<2, 32>(k, st) : launch_wgp<2, 16>(k, st);
     if (name) *name = a->stride == 1 ? (tx == 32 ? "k_wgrad_patch<s1,2x32>" : "k_wgrad_patch<s1,4x16>")

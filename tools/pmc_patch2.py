@@ -14,3 +14,10 @@ for mode, srcs, w, n, grid, oshape in cases:
     for _ in range(3):
         K.gather_gemm(mode, srcs, w, n, [o], grid, ws, stats=True)
     torch.cuda.synchronize()
+# weight gradients on the patch kernel: c4 (stride 1) and e3/c3 (stride 2)
+for (dh, dw_, dc), (gh, gw, gc), stride in (((31, 31, 512), (32, 32, 256), 1), ((32, 32, 256), (64, 64, 128), 2)):
+    d = [T(B, dh, dw_, dc)]; g = [T(B, gh, gw, gc)]
+    dwt = torch.zeros(dc * 16 * gc, device='cuda')
+    for _ in range(3):
+        K.wgrad(d, g, dwt, stride, [dc], [gc], ws=ws)
+    torch.cuda.synchronize()

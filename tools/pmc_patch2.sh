@@ -23,7 +23,7 @@ for d in sorted(glob.glob(O + '/pass*/')):
     for r in csv.DictReader(open(fs[0])):
         k = (r['Kernel_Name'][:60], r['Dispatch_Id'] if 'Dispatch_Id' in r else r.get('Correlation_Id'))
         name = r['Kernel_Name']
-        if 'k_conv' not in name: continue
+        if 'k_conv' not in name and 'k_wgrad' not in name and 'k_tconv4' not in name: continue
         acc.setdefault(name[:70], collections.OrderedDict()).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
 for k, cs in acc.items():
     print(k)
