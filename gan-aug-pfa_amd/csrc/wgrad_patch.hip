@@ -66,12 +66,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     constexpr int PP = (PSLOTS * 8 + 511) / 512;                          // DMA passes of the patch
     constexpr int PATCH_BYTES = PP * 8192;
     constexpr int STAGE = DIR_BYTES + PATCH_BYTES;
-    constexpr int NOPS = 2 + PP;                                          // DMA instructions per wave and step
+    constexpr int NOPS = 2 + PP;                                          // DMA instructions per wave and step (at most)
+    // the last patch pass covers PSLOTS * 8 - (PP - 1) * 512 lanes: only its first LASTW waves issue it (the DMA is priced per
+    // instruction: on 7 of 8 waves one of 4-5 instructions per step disappears)
+    constexpr int LASTW = (PSLOTS * 8 - (PP - 1) * 512 + 63) / 64;
+    static_assert(LASTW >= 1 && LASTW <= 8, "last patch pass");
     static_assert(NSTAGE * STAGE <= 163840, "LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 1, kx = wave >> 1;
+    const bool last_pass = wave < LASTW;                     // (wave-uniform) this wave issues the last patch pass
     // work list: (c tile, ky, i tile) fastest - the workgroups of one pixel slice share both operands' pixels - then slice
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);
     const int ct = wid % p.ctiles; wid /= p.ctiles;
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(sbase + (k * 512 + wave * 64) * 16), 16, 0, 0);
             } else {
                 const int j = k - 2;
+                if (j == PP - 1 && !last_pass) continue;
                 const unsigned f = (g_flag >> (5 * j)) & 31u;
                 const bool ok = live && (f & (emask | 16u)) == 0;
                 const char* tb = p.gat + ((long long)(d_img * p.hg + STRIDE * qy0) * p.wg + STRIDE * qx0) * p.gp * 2;
@@ -264,8 +270,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         kstep(std::integral_constant<int, 1>{});
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
-        if (issue) { advance(); wait_vm<NOPS>(); }
-        else wait_vm<0>();
+        if (issue) {
+            advance();
+            if (no_dma) wait_vm<0>();
+            else if (last_pass) wait_vm<NOPS>();
+            else wait_vm<NOPS - 1>();
+        } else wait_vm<0>();
     };
     for (int i = 0; i < nsteps; i += 4) {
         body(i, std::integral_constant<int, 0>{}, true);
