@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--replay", action="store_true",
                     help="GanTrainer(use_graph='replay'): the step's launches recorded once as launch lists and re-issued "
                          "from C (pfa_replay) on the same three streams")
+    ap.add_argument("--grad-bf16", action="store_true",
+                    help="N > 1: the gradient all-reduces carry bfloat16 (GanTrainer(grad_payload='bf16')); default float32")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
     ap.add_argument("--no-early-real", action="store_true",
@@ -385,7 +387,8 @@ def main():
     disc = pfa_gan.NLayerDiscriminator(6).cuda()
     # inputs_resident: the batches below are packed and complete in HBM before the first step (the bench contract)
     trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph="auto" if args.auto_graph else ("replay" if args.replay else args.graph),
-                                 overlap=not args.no_overlap, inputs_resident=not args.no_early_real)
+                                 overlap=not args.no_overlap, inputs_resident=not args.no_early_real,
+                                 grad_payload="bf16" if args.grad_bf16 else None)
     if world > 1:                                    # rank 0's parameters and buffers are the job's
         for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
             torch.distributed.broadcast(t, 0)
@@ -443,6 +446,7 @@ def main():
             "config": {"workload": f"{args.size}x{args.size} RGB Pix2Pix G+D step (UNetGenerator num_downs=7 ngf=64 + "
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "grad_payload": "bf16" if trainer.grad_payload else "f32",
                        "launch": "hipGraph x3 segments" if trainer.use_graph is True else
                                  (("launch lists (pfa_replay), " if trainer.use_graph == "replay" else "eager, ") +
                                   ("3 HIP streams" if not args.no_overlap else "1 HIP stream")),

@@ -7,6 +7,8 @@ tensor produced by the HIP engine.  Checks (each rank):
   * parameters and Adam moments are bit-identical on both ranks after every step (same reduced gradient everywhere);
   * the update equals the one a single process computes from the MEAN of the two ranks' local gradients
     (train_gan.py:55-75 per rank, gradients averaged), recomputed here without a process group.
+PFA_DP_PAYLOAD=bf16: the gradient ranges travel as bfloat16 (GanTrainer(grad_payload="bf16")); the checks are the same - Adam's
+first steps move a parameter by ~lr * sign(g), which bf16 rounding of g does not change beyond the stated tolerance.
 PFA_DP_RESIDENT=1: three pre-packed steps enqueued back to back with GanTrainer(inputs_resident=True) - the next step's
 D(real) pass starts under the current step's tail - compared after the last one.
 """
@@ -43,7 +45,7 @@ def main():
     # rank r starts from DIFFERENT weights; the broadcast must make rank 0's the job's
     G, D = build(21 + rank, 31 + rank, nd, ngf, ndf)
     tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=dist.group.WORLD, overlap=overlap,
-                            inputs_resident=resident)
+                            inputs_resident=resident, grad_payload=os.environ.get("PFA_DP_PAYLOAD") or None)
     pfa_gan.broadcast_model(G, dist.group.WORLD)
     pfa_gan.broadcast_model(D, dist.group.WORLD)
     tr.G.refresh_shadows(force=True)

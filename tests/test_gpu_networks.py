@@ -376,12 +376,15 @@ def _torchrun(script_args, env_extra, timeout=600):
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
 
 
-@pytest.mark.parametrize("overlap", ["1", "0", "resident"], ids=["three-streams", "one-stream", "resident-inputs"])
+@pytest.mark.parametrize("overlap", ["1", "0", "resident", "bf16"],
+                         ids=["three-streams", "one-stream", "resident-inputs", "bf16-payload"])
 def test_data_parallel_two_ranks_on_device(overlap):
     """Two ranks, device tensors, the HIP engine: parameters stay identical across ranks and equal the single-process
-    update from the mean gradient (tests/dp_gpu_worker.py; gloo transport because the box has one GPU)."""
+    update from the mean gradient (tests/dp_gpu_worker.py; gloo transport because the box has one GPU).  bf16-payload: the
+    gradient ranges cross the ranks as bfloat16 (GanTrainer(grad_payload="bf16"))."""
     import os
-    env = {"PFA_DP_OVERLAP": "1", "PFA_DP_RESIDENT": "1"} if overlap == "resident" else {"PFA_DP_OVERLAP": overlap}
+    env = {"PFA_DP_OVERLAP": "1", "PFA_DP_RESIDENT": "1"} if overlap == "resident" else \
+        {"PFA_DP_OVERLAP": "1", "PFA_DP_PAYLOAD": "bf16"} if overlap == "bf16" else {"PFA_DP_OVERLAP": overlap}
     r = _torchrun([os.path.join(os.path.dirname(__file__), "dp_gpu_worker.py")], env)
     assert r.returncode == 0 and "DP_GPU_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
