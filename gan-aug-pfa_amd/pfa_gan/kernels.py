@@ -277,6 +277,10 @@ _FORCE_WS = None
 
 
 WGRAD_FRESH = _os.environ.get("PFA_WGRAD_FRESH", "1") != "0"       # A/B switch
+# Reduction slices from which a slab + ordered reduce is used instead of float atomics.  3: measured faster than atomics from
+# 4 slices on (e4 47 -> 36 us, c4 90 -> 81, d4 62 -> 54) and slower at 2 (e5 28 -> 37); and two atomic adds into a zeroed
+# buffer commute, so from 3 on every weight gradient is bitwise reproducible run to run.
+WGRAD_SLAB_MIN = int(_os.environ.get("PFA_WGRAD_SLAB_MIN", "3"))
 
 
 def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None, fresh=False):
@@ -313,9 +317,8 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None, fres
     slices = lib().pfa_wgrad_slices(ctypes.byref(a))       # (the library may route the call to a kernel with its own slicing)
     if slices < 0:
         check(slices, "pfa_wgrad_slices")
-    if ws is not None and (slices >= 8 or ws is FORCE_SLAB):
-        # many reduction slices over a small dw: per-slice slabs + an ordered reduce beat ~1.3 TB/s float atomics
-        # (and are reproducible); with a few slices over a large dw the atomics are as fast and need no workspace
+    if ws is not None and (slices >= WGRAD_SLAB_MIN or ws is FORCE_SLAB):
+        # per-slice slabs + an ordered reduce beat ~1.3 TB/s float atomics (and are reproducible)
         a.slab = ptr((ws if ws is not FORCE_SLAB else _FORCE_WS).get("wgslab", lib().pfa_wgrad_slab_floats(ctypes.byref(a))))
     check(lib().pfa_wgrad(ctypes.byref(a), stream()), "pfa_wgrad")
 
