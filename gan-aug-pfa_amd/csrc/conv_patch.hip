@@ -14,9 +14,11 @@
 //
 // Called by pfa_gather_gemm for the launches it fits (conv_s1_patch_ok); results equal the implicit GEMM's up to the order
 // of the float32 sums (channel chunk outer, tap inner instead of tap outer).
-#include "pfa_common.h"
+#include "patch_epilogue.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define PATCH_WAIT_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 template <int OFF> __device__ __forceinline__ bf16x8 lds_read16o(unsigned addr) {
@@ -24,19 +26,6 @@ template <int OFF> __device__ __forceinline__ bf16x8 lds_read16o(unsigned addr) 
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
-template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
-    const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
-    return v + __int_as_float(sh);
-}
-__device__ __forceinline__ float row_sum16(float v) {      // sum over a DPP row, valid in its last lane
-    v = dpp_add<0x111>(v);
-    v = dpp_add<0x112>(v);
-    v = dpp_add<0x114>(v);
-    v = dpp_add<0x118>(v);
-    return v;
-}
-
 struct PatchK {
     const char* src;     // [nb][hin][win][cin] bf16
     const char* w;       // [n][16][cin] bf16
@@ -250,6 +239,169 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
 }
 
+
+// ---- the same walk on MFMA 32x32x16 (round 2).  With 16x16x32 operands a ds_read_b128 lane group mixes two k-chunks of 16
+// pixels, which collide on the 144-byte pixel pitch: SQ_LDS_BANK_CONFLICT was 33 % of this kernel's LDS-active cycles.  With
+// 32x32x16 all 16 lanes of a group read the SAME k-chunk of 16 (of 32) consecutive pixels: 16 distinct bank slots.  A wave
+// owns 64 pixels (patch rows wm*2, wm*2+1) x 64 channels = 2 x 2 tiles; a step is four k-steps (16 reads, 16 MFMAs).  The
+// accumulators leave through the whole-row epilogue of patch_epilogue.h (K-slice planes, statistics, bf16 rows).
+struct Patch32K {
+    GatherK g;           // src1, w, out1 / slab / psum / psq, n, splitk ... as pfa_gather_gemm prepared them
+    int hin, win, cin, hout, wout, tiles_y, tiles_x, ntiles, nwg;
+    int org, flip, cper;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_s1_patch32(const Patch32K q) {
+    const GatherK& p = q.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;                 // 4 x 2 waves, 64 pixels x 64 channels per wave
+    const int lr = lane & 31, lh = lane >> 5;
+    unsigned wid = xcd_remap(blockIdx.x, q.nwg);
+    const int nt = wid % q.ntiles; wid /= q.ntiles;
+    const int split = wid % p.splitk; wid /= p.splitk;
+    const int tx = wid % q.tiles_x; wid /= q.tiles_x;
+    const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
+    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
+    const char* zero = (const char*)g_pfa_zero_page;
+
+    unsigned poff[PPASS];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) {
+        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
+        const int py = slot / PW, px = slot - py * PW;
+        const int iy = oy0 - q.org + py, ix = ox0 - q.org + px;
+        const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)q.hin && (unsigned)ix < (unsigned)q.win;
+        poff[j] = ok ? (unsigned)((((img * q.hin + iy) * q.win + ix) * q.cin + g * 8) * 2) : 0u;
+        pok |= ok ? (1u << j) : 0u;
+    }
+    const int c0 = split * q.cper;
+    auto stage_patch_piece = [&](int chunk, int j) {
+        const char* gp = ((pok >> j) & 1u) ? p.src1 + poff[j] + (c0 + chunk) * 128 : zero;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    const int cs = tid & 7, r0 = tid >> 3;
+    const int wg = cs ^ ((r0 >> 1) & 7);
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
+    auto stage_w = [&](int step, int buf) {
+        const int chunk = c0 + (step >> 4), tap = q.flip ? 15 - (step & 15) : (step & 15);
+        char* wb = smem + 2 * PATCH_BYTES + buf * W_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* gp = p.w + woff[i] + (tap * q.cin + chunk * 64) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    int tpos[2];
+    unsigned abyte[2];               // activation tile b: patch row wm*2 + b, columns lr; k-chunk lh (+ 32 s per k-step)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        tpos[b] = (wm * 2 + b) * TX + lr;
+        abyte[b] = lds0 + ((wm * 2 + b) * PW + lr) * PSTRIDE + lh * 16;
+    }
+    unsigned wadr[4];                // weight rows wn*64 + lr (+ 32 a: offset 4096), swizzled chunk of k-step s
+    {
+        const int row = wn * 64 + lr;                         // (row + 32 has the same (row >> 1) & 7)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) wadr[s2] = lds0 + 2 * PATCH_BYTES + row * 128 + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    const int nchunks = q.cper, nsteps = nchunks * 16;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) stage_patch_piece(0, j);
+    stage_w(0, 0);
+    stage_w(1, 1);
+
+    bf16x8 wf[2][4], af[2][4];       // [tile][k-step]
+    const bool late = wave >= 4;
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nsteps; ++i) {
+        const int chunk = i >> 4, tap = i & 15;
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned tb = (chunk & 1) * PATCH_BYTES + ((tap >> 2) * PW + (tap & 3)) * PSTRIDE;
+            const unsigned rb = (i % 3) * W_BYTES;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const unsigned wa = wadr[s2] + rb;
+                wf[0][s2] = lds_read16o<0>(wa);
+                wf[1][s2] = lds_read16o<4096>(wa);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const unsigned aa = abyte[b] + tb;
+                af[b][0] = lds_read16o<0>(aa); af[b][1] = lds_read16o<32>(aa); af[b][2] = lds_read16o<64>(aa); af[b][3] = lds_read16o<96>(aa);
+            }
+        }
+        const bool pp = tap < PPASS && chunk + 1 < nchunks;
+        if (pp) stage_patch_piece(chunk + 1, tap);
+        if (i + 2 < nsteps) {
+            stage_w(i + 2, (i + 2) % 3);
+            if (pp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PATCH_WAIT_LGKM(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) { pin(wf[t][s2]); pin(af[t][s2]); }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a][s2], af[b][s2], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: accumulators -> fp32 [position][channel] image in LDS -> whole rows (patch_epilogue.h)
+    constexpr int RS = patch_image_stride<128>();
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        char* row = smem + tpos[b] * RS;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(row + (wn * 64 + a * 32 + 8 * g + 4 * lh) * 4) = v;
+            }
+    }
+    __syncthreads();
+    auto pix_of = [&](int r, bool& valid, size_t& opix) {
+        const int oy = oy0 + r / TX, ox = ox0 + r % TX;
+        valid = oy < q.hout && ox < q.wout;
+        opix = valid ? ((size_t)img * q.hout + oy) * q.wout + ox : 0;
+    };
+    const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
+    patch_epilogue_rows<128>(p, n0, tid, split, trow, smem, pix_of);
+}
+
 }  // namespace
 
 // Geometry the patch kernel is built for (the caller has already checked: bf16, one source, one unpadded output, no bias /
@@ -278,5 +430,28 @@ int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float
     }
     hipLaunchKernelGGL(k_conv_s1_patch, dim3(k.nwg), dim3(512), LDS_BYTES, st, k);
     PFA_LAUNCHED("k_conv_s1_patch");
+    return 0;
+}
+
+// The 32x32x16 form of the kernel (the default): `k` as pfa_gather_gemm prepared it for the launch (K-sliced: bias / statistics
+// already moved to the finish pass).
+int pfa_conv_s1_patch32(int grad, const GatherK& k, int hin, int win, int cin, hipStream_t st) {
+    Patch32K q;
+    q.g = k;
+    q.hin = hin; q.win = win; q.cin = cin;
+    q.hout = grad ? hin + 1 : hin - 1; q.wout = grad ? win + 1 : win - 1;
+    q.org = grad ? 2 : 1; q.flip = grad ? 1 : 0;
+    q.cper = cin / 64 / k.splitk;
+    q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / 128;
+    q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
+    constexpr int OUT_BYTES = 256 * patch_image_stride<128>();
+    static_assert(OUT_BYTES <= LDS_BYTES, "the epilogue image fits the staging area");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_conv_s1_patch32, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_conv_s1_patch32, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
+    PFA_LAUNCHED("k_conv_s1_patch32");
     return 0;
 }

@@ -1199,8 +1199,11 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     hipEvent_t te0, te1;
     const bool timing = pfa_timing_begin(st, &te0, &te1);
     if (patch) {
-        rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
-                               a->nb, a->hs, a->ws, a->c1, a->n, st);
+        if (pfa_knob(3) == 6)           // knob 3 = 6: the 16x16x32 form (A/B)
+            rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
+                                   a->nb, a->hs, a->ws, a->c1, a->n, st);
+        else
+            rc = pfa_conv_s1_patch32(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, kk, a->hs, a->ws, a->c1, st);
         g_last_gather_name = "k_conv_s1_patch<bf16,8x32,128>";
     } else if (image) {
         const char* nm = "";

@@ -2,8 +2,9 @@
 import csv, glob, re, sys
 d = sys.argv[1]
 rows = sorted(csv.DictReader(open(glob.glob(f'{d}/*/*_kernel_trace.csv')[0])), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_adam(' in r['Kernel_Name'] and int(r['Grid_Size_X']) > 256 * 1000]
-start, end = idx[-3] + 1, idx[-1] + 1
+# one step = from one k_l1_tanh_bwd launch (exactly one per step) to the next: a full cycle of the schedule, starting mid-step
+idx = [i for i, r in enumerate(rows) if 'l1_tanh_bwd' in r['Kernel_Name']]
+start, end = idx[-2], idx[-1]
 seg = rows[start:end]
 t0 = int(seg[0]['Start_Timestamp'])
 sid = {}
@@ -23,3 +24,19 @@ for r in seg:
     prev_end[s] = e
     print(f"s{s} {b/1e3:8.1f} +{(e-b)/1e3:6.1f} gap{gap/1e3:6.1f}  {short(r['Kernel_Name']):44s} grid {int(r['Grid_Size_X'])//int(r['Workgroup_Size_X'])}")
 print("step wall us", (int(seg[-1]['End_Timestamp']) - t0) / 1e3)
+# per-stream busy time and the union of busy intervals (GPU time with at least one kernel running)
+iv = sorted((int(r['Start_Timestamp']) - t0, int(r['End_Timestamp']) - t0) for r in seg)
+busy, cur_s, cur_e = 0, None, None
+for b, e in iv:
+    if cur_e is None or b > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = b, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+per = {}
+for r in seg:
+    s_ = sid[r['Stream_Id']]
+    per[s_] = per.get(s_, 0) + int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+print("launches", len(seg), "sum of durations us", sum(per.values()) / 1e3, "per stream us", {k: round(v / 1e3, 1) for k, v in sorted(per.items())},
+      "at least one kernel running us", busy / 1e3)
