@@ -245,13 +245,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 // 32x32x16 all 16 lanes of a group read the SAME k-chunk of 16 (of 32) consecutive pixels: 16 distinct bank slots.  A wave
 // owns 64 pixels (patch rows wm*2, wm*2+1) x 64 channels = 2 x 2 tiles; a step is four k-steps (16 reads, 16 MFMAs).  The
 // accumulators leave through the whole-row epilogue of patch_epilogue.h (K-slice planes, statistics, bf16 rows).
+template <int N> __device__ __forceinline__ void wait_vmc() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 struct Patch32K {
     GatherK g;           // src1, w, out1 / slab / psum / psq, n, splitk ... as pfa_gather_gemm prepared them
     int hin, win, cin, hout, wout, tiles_y, tiles_x, ntiles, nwg;
     int org, flip, cper;
 };
 
+// BN: 128 or 64 output channels per workgroup (64: the launches whose 128-channel tiles alone would leave half the chip idle -
+// c4's input gradient - run un-sliced on twice the workgroups instead of K-sliced through float32 partial planes)
+template <int BN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_s1_patch32(const Patch32K q) {
+    constexpr int FN = BN / 64, WP = BN / 64, WB = BN * 128;      // weight tiles per wave, DMA pieces per lane, bytes per stage
     const GatherK& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int split = wid % p.splitk; wid /= p.splitk;
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
-    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
+    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * BN;
     const char* zero = (const char*)g_pfa_zero_page;
 
     unsigned poff[PPASS];
@@ -284,22 +290,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     };
     const int cs = tid & 7, r0 = tid >> 3;
     const int wg = cs ^ ((r0 >> 1) & 7);
-    unsigned woff[2];
+    unsigned woff[WP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
+    for (int i = 0; i < WP; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
     auto stage_w = [&](int step, int buf) {
         const int chunk = c0 + (step >> 4), tap = q.flip ? 15 - (step & 15) : (step & 15);
-        char* wb = smem + 2 * PATCH_BYTES + buf * W_BYTES;
+        char* wb = smem + 2 * PATCH_BYTES + buf * WB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WP; ++i) {
             const char* gp = p.w + woff[i] + (tap * q.cin + chunk * 64) * 2;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[FN][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -313,9 +319,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         tpos[b] = (wm * 2 + b) * TX + lr;
         abyte[b] = lds0 + ((wm * 2 + b) * PW + lr) * PSTRIDE + lh * 16;
     }
-    unsigned wadr[4];                // weight rows wn*64 + lr (+ 32 a: offset 4096), swizzled chunk of k-step s
+    unsigned wadr[4];                // weight rows wn*BN/2 + lr (+ 32 a: offset 4096), swizzled chunk of k-step s
     {
-        const int row = wn * 64 + lr;                         // (row + 32 has the same (row >> 1) & 7)
+        const int row = wn * (BN / 2) + lr;                   // (row + 32 has the same (row >> 1) & 7)
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) wadr[s2] = lds0 + 2 * PATCH_BYTES + row * 128 + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 4);
     }
@@ -326,9 +332,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     stage_w(0, 0);
     stage_w(1, 1);
 
-    bf16x8 wf[2][4], af[2][4];       // [tile][k-step]
+    bf16x8 wf[FN][4], af[2][4];      // [tile][k-step]
     const bool late = wave >= 4;
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    wait_vmc<WP>();                                           // patch 0 and weight stage 0 have landed
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();
     for (int i = 0; i < nsteps; ++i) {
@@ -336,12 +342,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         __builtin_amdgcn_sched_barrier(0);
         {
             const unsigned tb = (chunk & 1) * PATCH_BYTES + ((tap >> 2) * PW + (tap & 3)) * PSTRIDE;
-            const unsigned rb = (i % 3) * W_BYTES;
+            const unsigned rb = (i % 3) * WB;
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2) {
                 const unsigned wa = wadr[s2] + rb;
                 wf[0][s2] = lds_read16o<0>(wa);
-                wf[1][s2] = lds_read16o<4096>(wa);
+                if (FN > 1) wf[FN - 1][s2] = lds_read16o<4096>(wa);
             }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -353,23 +359,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (pp) stage_patch_piece(chunk + 1, tap);
         if (i + 2 < nsteps) {
             stage_w(i + 2, (i + 2) % 3);
-            if (pp) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (pp) wait_vmc<WP + 1>(); else wait_vmc<WP>();
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         PATCH_WAIT_LGKM(0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int s2 = 0; s2 < 4; ++s2) {
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) { pin(wf[t][s2]); pin(af[t][s2]); }
+            for (int t = 0; t < FN; ++t) pin(wf[t][s2]);
+            pin(af[0][s2]); pin(af[1][s2]);
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < FN; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a][s2], af[b][s2], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -379,17 +386,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     if (!late) __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: accumulators -> fp32 [position][channel] image in LDS -> whole rows (patch_epilogue.h)
-    constexpr int RS = patch_image_stride<128>();
+    constexpr int RS = patch_image_stride<BN>();
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         char* row = smem + tpos[b] * RS;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *(f32x4*)(row + (wn * 64 + a * 32 + 8 * g + 4 * lh) * 4) = v;
+                *(f32x4*)(row + (wn * (BN / 2) + a * 32 + 8 * g + 4 * lh) * 4) = v;
             }
     }
     __syncthreads();
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         opix = valid ? ((size_t)img * q.hout + oy) * q.wout + ox : 0;
     };
     const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
-    patch_epilogue_rows<128>(p, n0, tid, split, trow, smem, pix_of);
+    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of);
 }
 
 }  // namespace
@@ -433,25 +440,54 @@ int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float
     return 0;
 }
 
-// The 32x32x16 form of the kernel (the default): `k` as pfa_gather_gemm prepared it for the launch (K-sliced: bias / statistics
-// already moved to the finish pass).
-int pfa_conv_s1_patch32(int grad, const GatherK& k, int hin, int win, int cin, hipStream_t st) {
+// Plan of a stride-1 launch on the patch kernel: 128-channel tiles, un-sliced when they give the chip ~a workgroup per CU
+// (the caller's K slices are dropped: no float32 partial planes, the epilogue of the kernel does what the finish pass
+// would), else with the caller's K slices.  64-channel tiles would run c4's input gradient un-sliced on 256 workgroups, but
+// a step of this kernel's two-phase loop does not get shorter with half the MFMAs: 87 us against 73 us for the K-sliced
+// launch + finish pass (tools/s1_patch_ab.py) - they stay behind pfa_set_knob(3, 7).
+bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int splitk_caller, int* bn, int* splitk, int* stat_tiles) {
+    const int hout = grad ? hin + 1 : hin - 1, wout = grad ? win + 1 : win - 1;
+    if (cin % 64 || n % 64 || hout < 1 || wout < 1) return false;
+    const int tiles = nb * ((hout + TY - 1) / TY) * ((wout + TX - 1) / TX);
+    int b = 0, sk = 1;
+    if (n % 128 == 0 && (long long)tiles * (n / 128) >= 192) b = 128;
+    else if ((long long)tiles * (n / 64) >= 192 && pfa_knob(3) == 7) b = 64;          // knob 3 = 7 only: measured slower (below)
+    else if (n % 128 == 0) {
+        b = 128;
+        sk = splitk_caller < 1 ? 1 : splitk_caller;
+        if ((cin / 64) % sk) return false;
+    } else return false;
+    if (bn) *bn = b;
+    if (splitk) *splitk = sk;
+    if (stat_tiles) *stat_tiles = tiles;
+    return true;
+}
+
+// The 32x32x16 form of the kernel (the default): `k` as pfa_gather_gemm prepared it for the launch (k.splitk = the plan's;
+// K-sliced: bias / statistics already moved to the finish pass).
+template <int BN>
+static int launch_s1_patch32(const Patch32K& q, hipStream_t st) {
+    constexpr int LOOP_BYTES = 2 * PATCH_BYTES + 3 * BN * 128, OUT_BYTES = 256 * patch_image_stride<BN>();
+    constexpr int LDS = LOOP_BYTES > OUT_BYTES ? LOOP_BYTES : OUT_BYTES;
+    static_assert(LDS <= 163840, "LDS");
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k_conv_s1_patch32<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_conv_s1_patch32<BN>, dim3(q.nwg), dim3(512), LDS, st, q);
+    PFA_LAUNCHED("k_conv_s1_patch32");
+    return 0;
+}
+
+int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, int cin, hipStream_t st) {
     Patch32K q;
     q.g = k;
     q.hin = hin; q.win = win; q.cin = cin;
     q.hout = grad ? hin + 1 : hin - 1; q.wout = grad ? win + 1 : win - 1;
     q.org = grad ? 2 : 1; q.flip = grad ? 1 : 0;
     q.cper = cin / 64 / k.splitk;
-    q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / 128;
+    q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / bn;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
-    constexpr int OUT_BYTES = 256 * patch_image_stride<128>();
-    static_assert(OUT_BYTES <= LDS_BYTES, "the epilogue image fits the staging area");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_conv_s1_patch32, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(k_conv_s1_patch32, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
-    PFA_LAUNCHED("k_conv_s1_patch32");
-    return 0;
+    return bn == 128 ? launch_s1_patch32<128>(q, st) : launch_s1_patch32<64>(q, st);
 }

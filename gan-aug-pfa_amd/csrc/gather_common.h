@@ -56,7 +56,8 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan);
 int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, const char** kernel_name);
 
 // csrc/conv_patch.hip: the stride-1 patch kernel on MFMA 32x32x16 with the whole-row epilogue
-int pfa_conv_s1_patch32(int grad, const GatherK& k, int hin, int win, int cin, hipStream_t st);
+bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int splitk_caller, int* bn, int* splitk, int* stat_tiles);
+int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, int cin, hipStream_t st);
 
 // csrc/conv_image.hip: stride-2 convolution of the image-side layers (8-channel sources, 64 outputs)
 bool pfa_conv_image_ok(const GatherK& k, int dtype, int* stat_tiles);

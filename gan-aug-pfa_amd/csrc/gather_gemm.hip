@@ -959,17 +959,24 @@ inline int fill_params_geometry(const pfa_gather_args* a, GatherK& k, int& class
 // activation, at least 128 workgroups (smaller launches rely on more K slices than the channel chunks give).  A fused
 // epilogue rides on the finish pass, i.e. needs a K-sliced launch.  pfa_set_knob(3, 1) turns the route off, 2 takes it
 // whenever the geometry fits (tests).
-inline bool patch_route(const pfa_gather_args* a, const GatherK& k, int* tiles) {
+inline bool patch_route(const pfa_gather_args* a, const GatherK& k, int* tiles, int* bn_out = nullptr, int* splitk_out = nullptr) {
     if (pfa_knob(3) == 1) return false;
     if (!k.small32) return false;          // the patch kernel builds 32-bit byte offsets: tensors of 2 GiB and more stay on the implicit GEMM
     const bool fwd = a->mode == PFA_CONV_S1, grad = a->mode == PFA_CONV_S1_DGRAD;
     if (!((fwd || grad) && a->dtype == PFA_BF16 && a->c2 == 0 && a->bias == nullptr && a->act == PFA_ACT_NONE &&
-          a->n1 >= a->n && a->ld1 == a->n && a->ld2 == 0 && (a->fuse_out == 0 || (a->fuse_out != 3 && k.splitk > 1))))
+          a->n1 >= a->n && a->ld1 == a->n && a->ld2 == 0 && a->fuse_out != 3 && a->fuse_out != PFA_FUSE_DEFER))
         return false;
-    int t = 0;
-    if (!pfa_conv_s1_patch_ok(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &t)) return false;
-    if (pfa_knob(3) != 2 && (long long)t * (a->n / 128) * k.splitk < 128) return false;
+    int t = 0, bn = 128, sk = k.splitk;
+    if (pfa_knob(3) == 6) {                // the 16x16x32 form (A/B): 128-channel tiles, the caller's slices, fused epilogue only in the finish pass
+        if (!(a->fuse_out == 0 || k.splitk > 1)) return false;
+        if (!pfa_conv_s1_patch_ok(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &t)) return false;
+    } else if (!pfa_conv_s1_plan(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &bn, &sk, &t)) {
+        return false;
+    }
+    if (pfa_knob(3) != 2 && (long long)t * (a->n / bn) * sk < 128) return false;
     if (tiles) *tiles = t;
+    if (bn_out) *bn_out = bn;
+    if (splitk_out) *splitk_out = sk;
     return true;
 }
 
@@ -985,8 +992,11 @@ extern "C" size_t pfa_gather_slab_floats(const pfa_gather_args* a) {
 extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     GatherK k; int classes;
     if (int rc = fill_params(a, k, classes)) return rc;
-    int ptiles = 0;
-    if (k.splitk == 1 && patch_route(a, k, &ptiles)) return ptiles;
+    int ptiles = 0, pbn = 128, psk = 1;
+    if (patch_route(a, k, &ptiles, &pbn, &psk)) {
+        if (psk == 1) return ptiles;
+        k.splitk = psk;
+    }
     int itiles = 0;
     if (k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles)) return itiles;
     Patch2Plan plan2;
@@ -1185,8 +1195,9 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     // them (the small maps this is for are its launches anyway)
     const bool defer = a->fuse_out == PFA_FUSE_DEFER;
     if (defer) k.fuse_out = 0;
-    int ptiles = 0;
-    const bool patch = !defer && patch_route(a, k, &ptiles);
+    int ptiles = 0, pbn = 128, psk = 1;
+    const bool patch = !defer && patch_route(a, k, &ptiles, &pbn, &psk);
+    if (patch) k.splitk = psk;                     // (un-sliced wherever the tiles alone fill the chip: never more than the caller's)
     int itiles = 0;
     const bool image = !defer && !patch && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles);
     Patch2Plan plan2;
@@ -1203,8 +1214,8 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
             rc = pfa_conv_s1_patch(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, a->src1, a->w, a->out1, k.slab, k.splitk, kk.psum, kk.psq,
                                    a->nb, a->hs, a->ws, a->c1, a->n, st);
         else
-            rc = pfa_conv_s1_patch32(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, kk, a->hs, a->ws, a->c1, st);
-        g_last_gather_name = "k_conv_s1_patch<bf16,8x32,128>";
+            rc = pfa_conv_s1_patch32(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, kk, pbn, a->hs, a->ws, a->c1, st);
+        g_last_gather_name = pbn == 128 ? "k_conv_s1_patch<bf16,8x32,128>" : "k_conv_s1_patch<bf16,8x32,64>";
     } else if (image) {
         const char* nm = "";
         rc = pfa_conv_image(kk, st, &nm);
