@@ -16,6 +16,9 @@
 // of the float32 sums (channel chunk outer, tap inner instead of tap outer).
 #include "patch_epilogue.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -409,6 +412,197 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of);
 }
 
+// ---- the same kernel with the K loop of conv_patch2.hip / conv_tconv4.hip: ONE barrier per tap step, one fragment set
+// re-read in place a step ahead (counted lgkmcnt), the 16 tap bodies compiled once each (tap offset = immediate).  The two-phase
+// loop above spends ~1750 cycles per step on this tile, the in-place loop ~1540 on the stride-2 kernels.  160 KiB hold two
+// patch buffers and THREE weight stages, so the weight slot is a run-time offset (four address adds per step) and a stage
+// is prefetched two steps ahead: stage i+2 is issued at the start of step i into the slot stage i-1 left (its reads retired
+// during step i-1) and waited for at the end of step i, before the barrier behind which step i+1 reads it ahead.
+template <int OFF> __device__ __forceinline__ void s1_rd(unsigned addr, bf16x8& v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF));
+}
+constexpr int s1_tap_off(int v) { return ((v >> 2) * PW + (v & 3)) * PSTRIDE; }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_s1_inplace(const Patch32K q) {
+    constexpr int FN = 2, FM = 2, KS = 4, NR = FN + FM;
+    const GatherK& p = q.g;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2;
+    const int lr = lane & 31, lh = lane >> 5;
+    unsigned wid = xcd_remap(blockIdx.x, q.nwg);
+    const int nt = wid % q.ntiles; wid /= q.ntiles;
+    const int split = wid % p.splitk; wid /= p.splitk;
+    const int tx = wid % q.tiles_x; wid /= q.tiles_x;
+    const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
+    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
+    const char* zero = (const char*)g_pfa_zero_page;
+
+    unsigned poff[PPASS];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) {
+        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
+        const int py = slot / PW, px = slot - py * PW;
+        const int iy = oy0 - q.org + py, ix = ox0 - q.org + px;
+        const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)q.hin && (unsigned)ix < (unsigned)q.win;
+        poff[j] = ok ? (unsigned)((((img * q.hin + iy) * q.win + ix) * q.cin + g * 8) * 2) : 0u;
+        pok |= ok ? (1u << j) : 0u;
+    }
+    const int c0 = split * q.cper;
+    auto stage_patch_piece = [&](int chunk, int j) {
+        const char* gp = ((pok >> j) & 1u) ? p.src1 + poff[j] + (c0 + chunk) * 128 : zero;
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    };
+    const int cs = tid & 7, r0 = tid >> 3;
+    const int wg = cs ^ ((r0 >> 1) & 7);
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
+    auto stage_w = [&](int step, unsigned slot_off) {         // step = chunk * 16 + tap position
+        const int chunk = c0 + (step >> 4), tap = q.flip ? 15 - (step & 15) : (step & 15);
+        char* wb = smem + 2 * PATCH_BYTES + slot_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char* gp = p.w + woff[i] + (tap * q.cin + chunk * 64) * 2;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    int tpos[FM];
+    unsigned abuf[2][FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        tpos[b] = (wm * 2 + b) * TX + lr;
+        abuf[0][b] = lds0 + ((wm * 2 + b) * PW + lr) * PSTRIDE + lh * 16;
+        abuf[1][b] = abuf[0][b] + PATCH_BYTES;
+    }
+    unsigned wadr[KS];
+    {
+        const int row = wn * 64 + lr;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) wadr[s2] = lds0 + 2 * PATCH_BYTES + row * 128 + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 4);
+    }
+    bf16x8 fw[FN][KS], fa[FM][KS];
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) fw[a][s2] = bf16x8{};
+#pragma unroll
+        for (int b = 0; b < FM; ++b) fa[b][s2] = bf16x8{};
+    }
+    // reads of k-step S2 of the step at tap position V: weight addresses wv[] (slot already added), activation bases ab[]
+    auto read_kstep = [&](auto v_, auto s2_, const unsigned (&ab)[FM], const unsigned (&wv)[KS]) {
+        constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value;
+        s1_rd<0>(wv[S2], fw[0][S2]);
+        s1_rd<4096>(wv[S2], fw[1][S2]);
+#pragma unroll
+        for (int b = 0; b < FM; ++b) s1_rd<s1_tap_off(V) + S2 * 32>(ab[b], fa[b][S2]);
+    };
+
+    const int nsteps = q.cper * 16;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) stage_patch_piece(0, j);
+    stage_w(0, 0);
+    stage_w(1, W_BYTES);
+    wait_vmc<0>();
+    __builtin_amdgcn_s_barrier();
+    unsigned acur[FM] = {abuf[0][0], abuf[0][1]}, aoth[FM] = {abuf[1][0], abuf[1][1]};
+    // weight slot offsets of stage i (being computed), i+1 (read ahead during step i), i+2 (filled during step i)
+    unsigned w_cur = 0, w_nxt = W_BYTES, w_fil = 2 * W_BYTES;
+    {
+        unsigned wv[KS];
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) wv[s2] = wadr[s2] + w_cur;
+        read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, acur, wv);
+        read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, acur, wv);
+        read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, acur, wv);
+        read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, acur, wv);
+    }
+
+    auto body = [&](int i, auto v_, const bool more) {
+        constexpr int V = decltype(v_)::value, NV = (V + 1) & 15;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int chunk = i >> 4;
+        const bool w_issued = i + 2 < nsteps;
+        const bool p_issued = V < PPASS && chunk + 1 < q.cper;
+        unsigned wv[KS];                                     // the next step's weight fragment addresses
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) wv[s2] = wadr[s2] + w_nxt;
+        auto kstep = [&](auto s2_) {
+            constexpr int S2 = decltype(s2_)::value;
+            if (more) PATCH_WAIT_LGKM((KS - 1) * NR); else PATCH_WAIT_LGKM((KS - 1 - S2) * NR);
+#pragma unroll
+            for (int a = 0; a < FN; ++a) pin(fw[a][S2]);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) pin(fa[b][S2]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int b = 0; b < FM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a][S2], fa[b][S2], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (V == 15) read_kstep(std::integral_constant<int, NV>{}, s2_, aoth, wv);
+                else read_kstep(std::integral_constant<int, NV>{}, s2_, acur, wv);
+            }
+            if (S2 == 0 && w_issued) stage_w(i + 2, w_fil);
+            if (S2 == 2 && p_issued) stage_patch_piece(chunk + 1, V < PPASS ? V : 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{});
+        kstep(std::integral_constant<int, 3>{});
+        // stage i+2 (issued at k-step 0) has landed; a patch piece issued behind it may stay in flight
+        if (p_issued) wait_vmc<1>(); else wait_vmc<0>();
+        const unsigned t = w_cur; w_cur = w_nxt; w_nxt = w_fil; w_fil = t;
+    };
+    for (int i = 0; i < nsteps; i += 16) {
+        const bool next = i + 16 < nsteps;
+        [&]<int... V>(std::integer_sequence<int, V...>) {
+            (body(i + V, std::integral_constant<int, V>{}, V < 15 || next), ...);
+        }(std::make_integer_sequence<int, 16>{});
+#pragma unroll
+        for (int b = 0; b < FM; ++b) { const unsigned t = acur[b]; acur[b] = aoth[b]; aoth[b] = t; }
+    }
+
+    constexpr int RS = patch_image_stride<128>();
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+        char* row = smem + tpos[b] * RS;
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+                *(f32x4*)(row + (wn * 64 + a * 32 + 8 * g + 4 * lh) * 4) = v;
+            }
+    }
+    __syncthreads();
+    auto pix_of = [&](int r, bool& valid, size_t& opix) {
+        const int oy = oy0 + r / TX, ox = ox0 + r % TX;
+        valid = oy < q.hout && ox < q.wout;
+        opix = valid ? ((size_t)img * q.hout + oy) * q.wout + ox : 0;
+    };
+    const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
+    patch_epilogue_rows<128>(p, n0, tid, split, trow, smem, pix_of);
+}
+
 }  // namespace
 
 // Geometry the patch kernel is built for (the caller has already checked: bf16, one source, one unpadded output, no bias /
@@ -489,5 +683,15 @@ int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, in
     q.cper = cin / 64 / k.splitk;
     q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / bn;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
+    if (bn == 128 && pfa_knob(3) != 8) {                     // knob 3 = 8: the two-phase loop (A/B)
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)k_conv_s1_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_conv_s1_inplace, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
+        PFA_LAUNCHED("k_conv_s1_inplace");
+        return 0;
+    }
     return bn == 128 ? launch_s1_patch32<128>(q, st) : launch_s1_patch32<64>(q, st);
 }
