@@ -254,6 +254,7 @@ struct Patch32K {
     GatherK g;           // src1, w, out1 / slab / psum / psq, n, splitk ... as pfa_gather_gemm prepared them
     int hin, win, cin, hout, wout, tiles_y, tiles_x, ntiles, nwg;
     int org, flip, cper;
+    int order;           // work-list order of k_conv_s1_inplace (0: n-tile fastest, 1: n-tile slowest)
 };
 
 // BN: 128 or 64 output channels per workgroup (64: the launches whose 128-channel tiles alone would leave half the chip idle -
@@ -432,8 +433,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2;
     const int lr = lane & 31, lh = lane >> 5;
+    // work list: an XCD (private 4 MiB L2) takes a contiguous run of it.  order 0: n-tile fastest - the workgroups that share a
+    // patch sit together; order 1: n-tile slowest - an XCD streams ONE n-tile's weights (1 MiB for c4: resident in its L2)
+    // and every patch is fetched by as many XCDs as there are n-tiles
     unsigned wid = xcd_remap(blockIdx.x, q.nwg);
-    const int nt = wid % q.ntiles; wid /= q.ntiles;
+    int nt;
+    if (q.order == 0) { nt = wid % q.ntiles; wid /= q.ntiles; }
+    else { const unsigned per = q.nwg / q.ntiles; nt = wid / per; wid -= nt * per; }
     const int split = wid % p.splitk; wid /= p.splitk;
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
@@ -681,6 +687,7 @@ int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, in
     q.hout = grad ? hin + 1 : hin - 1; q.wout = grad ? win + 1 : win - 1;
     q.org = grad ? 2 : 1; q.flip = grad ? 1 : 0;
     q.cper = cin / 64 / k.splitk;
+    q.order = pfa_knob(5) == 1 ? 1 : 0;
     q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / bn;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
     if (bn == 128 && pfa_knob(3) != 8) {                     // knob 3 = 8: the two-phase loop (A/B)

@@ -61,16 +61,20 @@ uint64_t pfa_launch_count(void);
  * whenever the geometry fits);
  * id 3: the input-patch kernels (conv_patch.hip: stride-1 convolutions, forward and input gradient; conv_patch2.hip: stride-2
  * convolutions and transposed convolutions): 0 = launches large enough to fill the chip, 1 = never, 2 = whenever the geometry
- * fits, 3 = the stride-1 kernel only;
+ * fits, 3 = the stride-1 kernel only, 4 = no four-class transposed workgroups (conv_tconv4.hip), 5 = patch kernels and
+ * four-class workgroups whenever the geometry fits, 6 / 8 = the stride-1 kernel's earlier forms (two-phase loop on MFMA
+ * 16x16x32 / 32x32x16), 7 = 64-channel tiles for stride-1 launches whose 128-channel tiles leave the chip half empty;
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile, and of workgroups a stride-2 patch launch wants before it narrows its channel tile
  * or slices K (0 = defaults); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
- * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half). */
+ * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half), 11..17 = diagnostic instantiations of the
+ * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong. */
 int pfa_set_knob(int id, int value);
-/* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write four shader-clock
- * stamps per workgroup (entry, first fragments in registers, K loop done, stores accepted) as uint64[workgroups][4].
- * Never changes a result; off by default. */
+/* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write clock stamps per
+ * workgroup: conv (uint64[workgroups][16]: 8 shader-clock stamps - entry, first fragments, K loop done, accumulators in LDS,
+ * rows issued, statistics written, epilogue done, stores accepted - and 2 of the 100 MHz real-time counter) and weight
+ * gradient (uint64[workgroups][8]).  Never changes a result; off by default. */
 int pfa_set_debug_buffer(void* dev, size_t bytes);
 /* Kernel instantiation the calling thread's most recent pfa_gather_gemm launched, e.g. "k_gather_gemm<bf16,256,128,4,2,3>"
  * (tile rows, tile columns, wave grid, K-loop variant): lets a profiler script attribute a launch to a kernel name. */
