@@ -417,7 +417,7 @@ __global__ void k_adam_tick(int32_t* step) { *step += 1; }
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               const float* __restrict__ g2, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float lr, float b1, float b2,
-                                              float eps, int step, const int32_t* step_dev, float grad_scale) {
+                                              float eps, int step, const int32_t* step_dev, float grad_scale, int nt) {
     const int t = step_dev ? *step_dev : step;
     // torch: step_size = lr/(1-b1^t); denom = sqrt(v)/sqrt(1-b2^t) + eps
     const float bc1 = 1.f - powf(b1, (float)t);
@@ -425,7 +425,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     const float step_size = lr / bc1;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        // m and v are touched once per step and nowhere else: non-temporal, so that 650 MB of moments do not sweep the
+        // activations and weight copies the next kernels read out of the L2 / MALL (pfa_set_knob(1, 256) = plain, A/B)
+        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm, vv;
+        if (nt) { mm = __builtin_nontemporal_load((f32x4*)m + i); vv = __builtin_nontemporal_load((f32x4*)v + i); }
+        else { mm = ((f32x4*)m)[i]; vv = ((f32x4*)v)[i]; }
         if (g2) gg += ((const f32x4*)g2)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -434,7 +438,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
             vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
             pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) / bc2s + eps));
         }
-        ((f32x4*)p)[i] = pp; ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv;
+        ((f32x4*)p)[i] = pp;
+        if (nt) { __builtin_nontemporal_store(mm, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i); }
+        else { ((f32x4*)m)[i] = mm; ((f32x4*)v)[i] = vv; }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
@@ -759,7 +765,7 @@ extern "C" int pfa_adam(float* p, const float* g, const float* g2, float* m, flo
     PFA_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "pfa_adam: arenas must be 16-byte aligned");
     PFA_REQUIRE(!g2 || (uintptr_t)g2 % 16 == 0, "pfa_adam: second gradient arena must be 16-byte aligned");
     hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, g2, m, v, n, lr,
-                       beta1, beta2, eps, step, step_dev, grad_scale);
+                       beta1, beta2, eps, step, step_dev, grad_scale, (pfa_knob(1) & 256) ? 0 : 1);
     PFA_LAUNCHED("k_adam");
     return 0;
 }
