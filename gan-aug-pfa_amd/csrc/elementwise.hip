@@ -427,9 +427,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         // m and v are touched once per step and nowhere else: non-temporal, so that 650 MB of moments do not sweep the
         // activations and weight copies the next kernels read out of the L2 / MALL (pfa_set_knob(1, 256) = plain, A/B)
-        f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm, vv;
-        if (nt) { mm = __builtin_nontemporal_load((f32x4*)m + i); vv = __builtin_nontemporal_load((f32x4*)v + i); }
-        else { mm = ((f32x4*)m)[i]; vv = ((f32x4*)v)[i]; }
+        f32x4 pp = ((f32x4*)p)[i], gg, mm, vv;
+        if (nt) {
+            gg = nt & 2 ? __builtin_nontemporal_load((const f32x4*)g + i) : ((const f32x4*)g)[i];
+            mm = __builtin_nontemporal_load((f32x4*)m + i); vv = __builtin_nontemporal_load((f32x4*)v + i);
+        } else { gg = ((const f32x4*)g)[i]; mm = ((f32x4*)m)[i]; vv = ((f32x4*)v)[i]; }
         if (g2) gg += ((const f32x4*)g2)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -765,7 +767,7 @@ extern "C" int pfa_adam(float* p, const float* g, const float* g2, float* m, flo
     PFA_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "pfa_adam: arenas must be 16-byte aligned");
     PFA_REQUIRE(!g2 || (uintptr_t)g2 % 16 == 0, "pfa_adam: second gradient arena must be 16-byte aligned");
     hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, g2, m, v, n, lr,
-                       beta1, beta2, eps, step, step_dev, grad_scale, (pfa_knob(1) & 256) ? 0 : 1);
+                       beta1, beta2, eps, step, step_dev, grad_scale, (pfa_knob(1) & 256) ? 0 : ((pfa_knob(1) & 512) ? 3 : 1));
     PFA_LAUNCHED("k_adam");
     return 0;
 }
