@@ -425,6 +425,7 @@ class GeneratorEngine(_Engine):
         if H % (1 << D) or W % (1 << D):
             raise PfaError(f"input {H}x{W} must be a multiple of 2^num_downs = {1 << D}")
         ctx.v.update(x=x, aL={}, aR={}, uR={}, train=train)
+        K.set_phase(train)
         a = x
         for k in range(D):
             L = self.down[k]
@@ -496,6 +497,7 @@ class GeneratorEngine(_Engine):
         (the caller may all-reduce that range and update its parameters under the rest of the backward)."""
         if not ctx.v.get("train", False):
             raise PfaError("generator backward needs a training-mode forward")
+        K.set_phase(True)
         D, dt = self.D, self.dtype
         v = ctx.v
         B, H, W, _ = v["x"].shape
@@ -620,6 +622,7 @@ class DiscriminatorEngine(_Engine):
         dt = self.dtype
         B, H, W, _ = srcs[0].shape
         ctx.v.update(srcs=list(srcs), a={}, train=train)
+        K.set_phase(train)
         a, h, w = list(srcs), H, W
         n = len(self.layers)
         for i, L in enumerate(self.layers):
@@ -663,6 +666,7 @@ class DiscriminatorEngine(_Engine):
         arena of a first one)."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
+        K.set_phase(True)
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:

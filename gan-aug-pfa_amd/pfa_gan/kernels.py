@@ -107,6 +107,20 @@ class Workspace:
 
 
 # ------------------------------------------------------------------------------- gather GEMM
+# Workgroups a K-sliced launch aims for.  In-situ sweeps (bench.py, same box): the training step is fastest at 256 (512 ->
+# 3.41 ms, 256 -> 3.37, 128 -> 3.41, 64 -> 3.52: fewer float32 partial planes, and its other streams fill the CUs a launch
+# leaves idle), the single-stream eval forward at 512 (1.094 against 1.146 ms at B = 64).  The engines set the phase.
+SPLITK_TARGET = {True: int(__import__("os").environ.get("PFA_SPLITK_TARGET", "256")),
+                 False: int(__import__("os").environ.get("PFA_SPLITK_TARGET_EVAL", "512"))}
+_phase_train = True
+
+
+def set_phase(train):
+    """Called by the engines at the start of a forward / backward pass: training passes and eval forwards slice K differently."""
+    global _phase_train
+    _phase_train = bool(train)
+
+
 def choose_splitk(mode, M, n, ctot, dtype):
     """Slice K over extra workgroups when the output grid alone cannot fill 256 CUs
     (the bottleneck layers at 8x8 and below are weight-bandwidth bound, SURVEY 7 'Hard parts')."""
@@ -123,7 +137,7 @@ def choose_splitk(mode, M, n, ctot, dtype):
         return 2 if blocks < 384 and ksteps >= 32 and n % 4 == 0 else 1
     # enough slices for ~512 workgroups, at most 16 and a power of two: even slices (c5: 9 uneven slices 31 us, 8 slices
     # 24 us) and a bounded slab (the 2x2 / 4x4 layers: 32 slices 32 us, 8-16 slices 26 us; tools/tune_gather.py)
-    want = max(1, min(ksteps // 4, math.ceil(512 / blocks), 16))
+    want = max(1, min(ksteps // 4, math.ceil(SPLITK_TARGET[_phase_train] / blocks), 16))
     return 1 << (want.bit_length() - 1)
 
 
