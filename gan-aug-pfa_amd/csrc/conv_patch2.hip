@@ -387,7 +387,9 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
     const int classes = k.mode == PFA_TCONV_S2 ? 4 : 1;
     const long long tiles = (long long)k.nb * pl.tiles_y * pl.tiles_x * classes;
     const int nss = (k.ctot / 64) * (k.mode == PFA_CONV_S2 ? 4 : 1);
-    const int want = pfa_knob(6) > 0 ? pfa_knob(6) : 192;
+    // (in-situ sweep of the threshold: 192 -> 3.41 ms per step, 128 -> 3.37, 256 -> 3.47, 320 -> 3.65: a launch that leaves CUs
+    // idle is not lost inside the three-stream step, narrower tiles are)
+    const int want = pfa_knob(6) > 0 ? pfa_knob(6) : 128;
     pl.splitk = 1;
     if (k.n % 128 == 0 && tiles * (k.n / 128) >= want) pl.bn = 128;
     else if (tiles * (k.n / 64) >= want || k.splitk <= 1) pl.bn = 64;

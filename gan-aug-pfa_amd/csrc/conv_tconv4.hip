@@ -229,7 +229,7 @@ bool pfa_tconv4_ok(const GatherK& k, int dtype, int tiles_y, int tiles_x) {
     if (pfa_knob(3) == 4) return false;                      // knob 3 = 4: per-class workgroups only (A/B)
     if (dtype != PFA_BF16 || k.mode != PFA_TCONV_S2 || k.wq < 32 || k.ctot < 64) return false;
     if (pfa_knob(3) == 5) return true;                       // knob 3 = 5: whenever the geometry allows (tests)
-    return (long long)k.nb * tiles_y * tiles_x * (k.n / T4_BN) >= 192;
+    return (long long)k.nb * tiles_y * tiles_x * (k.n / T4_BN) >= (pfa_knob(9) > 0 ? pfa_knob(9) : 192);      // knob 9: the threshold
 }
 
 int pfa_tconv4(const GatherK& k, int tiles_y, int tiles_x, hipStream_t st, const char** kernel_name) {

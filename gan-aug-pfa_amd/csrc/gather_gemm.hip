@@ -20,7 +20,7 @@
 
 // developer knobs (pfa_set_knob): [0] gather tile config, [1] ablation bits, ... (include/pfa_hip.h).  Relaxed atomics: the
 // library may be entered from several host threads / streams at once; a knob is a measurement switch, never a result.
-std::atomic<int> g_knob[8];
+std::atomic<int> g_knob[16];
 static thread_local const char* g_last_gather_name = "";
 
 // Optional per-launch timing (pfa_gather_timing): HIP events recorded on the launch stream right before and right after the
@@ -1126,7 +1126,7 @@ extern "C" int pfa_set_debug_buffer(void* dev, size_t bytes) {
 }
 
 extern "C" int pfa_set_knob(int id, int value) {
-    PFA_REQUIRE(id >= 0 && id < 8, "pfa_set_knob: id out of range");
+    PFA_REQUIRE(id >= 0 && id < 16, "pfa_set_knob: id out of range");
     g_knob[id].store(value, std::memory_order_relaxed);
     return 0;
 }

@@ -42,7 +42,7 @@ extern std::atomic<uint64_t> g_pfa_launches;
     } while (0)
 
 // developer knobs and the per-launch timing store (csrc/gather_gemm.hip)
-extern std::atomic<int> g_knob[8];
+extern std::atomic<int> g_knob[16];
 static inline int pfa_knob(int i) { return g_knob[i].load(std::memory_order_relaxed); }
 bool pfa_timing_begin(hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);      // false: timing is off (or the store is full)
 void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk);

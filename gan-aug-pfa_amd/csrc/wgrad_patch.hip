@@ -370,7 +370,10 @@ bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int
     const int tx = a->wq >= 24 ? 32 : 16, ty = 64 / tx;
     const int steps = a->nb * ((a->hq + ty - 1) / ty) * ((a->wq + tx - 1) / tx);
     const int tiles = ((a->d1p + a->d2p) / 128) * 4 * (a->g1p / 64);
-    int ms = (256 + tiles - 1) / tiles;
+    // workgroups a launch aims for (knob 8).  In-situ sweep: 512 -> 3.39 ms per step, 256 -> 3.35, 192 -> 3.30, 128 -> 3.28,
+    // 96 -> 3.30, 64 -> 3.36: these launches share the GPU with the main stream, and fewer slices are fewer partial tiles
+    const int want = pfa_knob(8) > 0 ? pfa_knob(8) : 128;
+    int ms = (want + tiles - 1) / tiles;
     if (ms > steps / 4) ms = steps / 4;
     if (ms < 1) ms = 1;
     const int sper = (steps + ms - 1) / ms;
