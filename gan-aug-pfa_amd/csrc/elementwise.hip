@@ -766,7 +766,7 @@ extern "C" int pfa_adam(float* p, const float* g, const float* g2, float* m, flo
     PFA_REQUIRE(step_dev || step >= 1, "pfa_adam: step must be >= 1");
     PFA_REQUIRE(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "pfa_adam: arenas must be 16-byte aligned");
     PFA_REQUIRE(!g2 || (uintptr_t)g2 % 16 == 0, "pfa_adam: second gradient arena must be 16-byte aligned");
-    hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, (hipStream_t)s, p, g, g2, m, v, n, lr,
+    hipLaunchKernelGGL(k_adam, dim3(grid_for(n >> 2, 256, pfa_knob(11) > 0 ? pfa_knob(11) : 2048)), dim3(256), 0, (hipStream_t)s, p, g, g2, m, v, n, lr,
                        beta1, beta2, eps, step, step_dev, grad_scale, (pfa_knob(1) & 256) ? 0 : ((pfa_knob(1) & 512) ? 3 : 1));
     PFA_LAUNCHED("k_adam");
     return 0;

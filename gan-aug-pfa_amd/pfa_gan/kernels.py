@@ -285,6 +285,7 @@ def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE):
     check(lib().pfa_tconv_scatter(ctypes.byref(a), stream()), "pfa_tconv_scatter")
 
 
+WGRAD_MINSTEPS = int(_os.environ.get("PFA_WGRAD_MINSTEPS", "8"))   # reduction steps a slice keeps at least (A/B runs)
 WGRAD_BLOCKS = int(_os.environ.get("PFA_WGRAD_BLOCKS", "512"))     # workgroups a weight-gradient launch aims for (A/B runs)
 FORCE_SLAB = object()     # pass as ws= to force the slab combine whatever the slice count (tests)
 _FORCE_WS = None
@@ -322,7 +323,7 @@ def wgrad(direct, gathered, dw, stride, dreal, greal, msplit=None, ws=None, fres
         M = a.nb * a.hq * a.wq
         tiles = math.ceil(16 * (a.g1p + a.g2p) / 128) * math.ceil((a.d1p + a.d2p) / 128)
         # ~2 workgroups per CU; every extra slice costs one more float32-atomic pass over dw (chip-wide ~1.3 TB/s)
-        msplit = max(1, min(math.ceil(M / km / 8), math.ceil(WGRAD_BLOCKS / tiles)))
+        msplit = max(1, min(math.ceil(M / km / WGRAD_MINSTEPS), math.ceil(WGRAD_BLOCKS / tiles)))
     a.msplit = msplit
     a.fresh = 1 if fresh and WGRAD_FRESH else 0
     a.dir1, a.dir2 = ptr(direct[0]), ptr(direct[1]) if len(direct) > 1 else None
