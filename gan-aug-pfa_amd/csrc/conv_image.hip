@@ -17,7 +17,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct ImageK {
     GatherK g;
-    int tiles_y, tiles_x, nwg;
+    int tiles_y, tiles_x, ntiles, nwg;      // ntiles: 64-channel tiles of the output (n = 64 or 128)
 };
 
 constexpr int ITY = 8, ITX = 32;
@@ -38,9 +38,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 31, lh = lane >> 5;
     unsigned wid = blockIdx.x;
+    const int nt = wid % q.ntiles; wid /= q.ntiles;          // (the n-tiles of a patch are neighbours: the second finds it in L2)
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
-    const int qy0 = ty * ITY, qx0 = tx * ITX;
+    const int qy0 = ty * ITY, qx0 = tx * ITX, n0 = nt * 64;
     const char* zero = (const char*)g_pfa_zero_page;
 
     // ---- one round of DMA: the patch of every source (pieces dealt round-robin over the waves), then the weights.
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         for (int pc = wave; pc < WPIECES; pc += 8) {
             const int s = pc * 64 + lane, n = s / CPR, cpos = s - n * CPR;
             const int c = (cpos & ~15) | ((cpos ^ n) & 15);
-            const char* gp = n < p.n ? p.w + ((size_t)n * K + c * 8) * 2 : zero;
+            const char* gp = n0 + n < p.n ? p.w + ((size_t)(n0 + n) * K + c * 8) * 2 : zero;
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wl + pc * 1024), 16, 0, 0);
         }
     }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
     };
     const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
-    patch_epilogue_rows<64>(p, 0, tid, 0, trow, smem, pix_of);
+    patch_epilogue_rows<64>(p, n0, tid, 0, trow, smem, pix_of);
 }
 
 template <int NSRC>
@@ -139,12 +140,14 @@ int launch_image(const ImageK& k, hipStream_t st) {
 
 }  // namespace
 
-// bf16 PFA_CONV_S2 launches with 8-channel sources (one or two), n = 64 and no K slices, fused backward or tanh.
+// bf16 PFA_CONV_S2 launches with 8-channel sources (one or two), n = 64 or 128 (two 64-channel tiles per patch: the input
+// gradient of the generator's output layer, whose two halves are the skip gradient and the fused BatchNorm backward of d2),
+// no K slices, no tanh.
 bool pfa_conv_image_ok(const GatherK& k, int dtype, int* stat_tiles) {
     if (pfa_knob(3) == 1 || pfa_knob(3) == 3) return false;
     if (dtype != PFA_BF16 || k.mode != PFA_CONV_S2 || !k.small32) return false;
-    if (k.c1 != 8 || !(k.c2 == 0 || k.c2 == 8) || k.n != 64 || k.act == PFA_ACT_TANH) return false;
-    if (k.fuse_out == 1 || k.fuse_out == 2) return false;
+    if (k.c1 != 8 || !(k.c2 == 0 || k.c2 == 8) || !(k.n == 64 || k.n == 128) || k.act == PFA_ACT_TANH) return false;
+    if (k.fuse_out == PFA_FUSE_DEFER) return false;
     if (k.hq < 8 || k.wq < 16) return false;
     if (stat_tiles) *stat_tiles = k.nb * ((k.hq + ITY - 1) / ITY) * ((k.wq + ITX - 1) / ITX);
     return true;
@@ -155,7 +158,8 @@ int pfa_conv_image(const GatherK& k, hipStream_t st, const char** kernel_name) {
     q.g = k;
     q.g.splitk = 1;
     q.tiles_y = (k.hq + ITY - 1) / ITY; q.tiles_x = (k.wq + ITX - 1) / ITX;
-    q.nwg = k.nb * q.tiles_y * q.tiles_x;
+    q.ntiles = k.n / 64;
+    q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles;
     if (kernel_name) *kernel_name = k.c2 ? "k_conv_image<2x8ch,64>" : "k_conv_image<8ch,64>";
     return k.c2 ? launch_image<2>(q, st) : launch_image<1>(q, st);
 }

@@ -143,15 +143,18 @@ def choose_splitk(mode, M, n, ctot, dtype):
 
 import os as _os
 FUSE_BWD = _os.environ.get("PFA_FUSE_BWD", "1") != "0"     # A/B switch for the fused dgrad epilogue
+IMAGE_DGRAD_FUSE = _os.environ.get("PFA_IMAGE_DGRAD_FUSE", "1") != "0"   # A/B switch: fused backward on the image-side input gradient
 FUSE_SPLIT = _os.environ.get("PFA_FUSE_SPLIT", "1") != "0"  # ... and for fusing it into the finish pass of K-sliced launches
 
 
 def auto_splitk(mode, srcs, n, grid):
     if not FUSE_BWD:
         return 0            # "not 1": callers fall back to the separate backward-reduce pass
-    if sum(s.shape[3] for s in srcs) < 8 * ch_of(srcs[0].dtype):
-        # narrow source (the 3-channel image gradient): the fused epilogue doubles that short launch (104 vs 49 us in the
-        # step, tools/insitu_launches.py) while the separate streaming pass costs ~25 us
+    if sum(s.shape[3] for s in srcs) < 8 * ch_of(srcs[0].dtype) and not (
+            IMAGE_DGRAD_FUSE and mode == CONV_S2 and srcs[0].dtype == torch.bfloat16 and len(srcs) == 1 and n in (64, 128)):
+        # narrow source (the 3-channel image gradient) on the implicit GEMM: the fused epilogue doubles that short launch
+        # (104 vs 49 us in the step, tools/insitu_launches.py) while the separate streaming pass costs ~25 us.  In bf16 the
+        # launch runs on the image-side kernel (conv_image.hip), whose whole-row epilogue carries the fused backward cheaply.
         return 0
     return choose_splitk(mode, grid[0] * grid[1] * grid[2], n, sum(s.shape[3] for s in srcs), srcs[0].dtype)
 

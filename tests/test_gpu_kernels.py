@@ -447,7 +447,10 @@ def test_affine_epilogue(case, dtype, ws):
         kernel = _lib.lib().pfa_last_gather_kernel().decode()
     finally:
         _lib.lib().pfa_set_knob(3, 0)
-    assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
+    if name.startswith("img_"):
+        assert kernel.startswith("k_conv_image") == (dtype == torch.bfloat16), kernel
+    else:
+        assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
     close(from_nhwc(outs[0], co), ops.leaky_relu(y) if dual else ops.relu(y), dtype, name + " out1", scale=np.abs(y).max())
     if dual:
         close(from_nhwc(outs[1], co), ops.relu(y), dtype, name + " out2", scale=np.abs(y).max())
@@ -469,6 +472,10 @@ FUSED_BWD_CASES = [  # name, N, cin, H, W, Co (columns), K slices, BatchNorm, se
     ("p2_bn_g2", 2, [64], 32, 32, 128, 1, True, True, False),
     ("p2_two_outputs", 2, [64], 32, 32, 128, 1, True, False, True),
     ("p2_act_sliced", 2, [128], 32, 32, 64, 2, False, False, False),
+    # the input gradient of the generator's output layer: a 3-channel source (8 padded), 128 columns = [skip gradient 64 |
+    # fused BatchNorm backward 64]; in bf16 on the image-side kernel (conv_image.hip), two 64-channel tiles per patch
+    ("img_two_outputs", 2, [3], 32, 64, 128, 1, True, False, True),
+    ("img_act_only", 1, [3], 36, 80, 64, 1, False, False, False),
 ]
 
 
@@ -516,7 +523,10 @@ def test_fused_backward_epilogue(case, dtype, ws):
         kernel = _lib.lib().pfa_last_gather_kernel().decode()
     finally:
         _lib.lib().pfa_set_knob(3, 0)
-    assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
+    if name.startswith("img_"):
+        assert kernel.startswith("k_conv_image") == (dtype == torch.bfloat16), kernel
+    else:
+        assert kernel.startswith("k_conv_patch2") == (force and dtype == torch.bfloat16), kernel
     launches = _lib.launch_count() - before
     assert launches == (2 if slices > 1 else 1)
     amax = np.abs(g).max()
