@@ -180,6 +180,7 @@ class _Engine:
         self.device = self.flat.device
         self.ws = K.Workspace(self.device)           # main-stream scratch
         self.ws_side = K.Workspace(self.device)      # scratch of the parameter-gradient stream
+        self.ws_side_b = K.Workspace(self.device)    # ... of the second one when they alternate
         self.ws_alt = K.Workspace(self.device)       # scratch of a whole pass that runs on another stream
         self.ws_cur = self.ws
         self.layers = []
@@ -195,13 +196,26 @@ class _Engine:
         """Run a layer's parameter-gradient launches (wgrad, bias column sums).  They depend only on the layer's
         output gradient, so with a side stream they run concurrently with the dgrad / BatchNorm chain on the main
         stream (fork here; the caller joins before the optimizer).  Their workspace is not shared with the main
-        stream's kernels."""
+        stream's kernels.  side may be a pair of streams: consecutive layers then alternate between them (each with a
+        workspace of its own) and _join_sides() folds the second into the first before anything waits for `side`."""
         if side is None:
             fn(self.ws_cur)
             return
+        ws = self.ws_side
+        if isinstance(side, (tuple, list)):
+            self._side_turn = getattr(self, "_side_turn", 0) ^ 1
+            if self._side_turn and side[1] is not None:
+                side, ws = side[1], self.ws_side_b
+            else:
+                side = side[0]
         K.wait_stream(side, torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            fn(self.ws_side)
+            fn(ws)
+
+    @staticmethod
+    def _join_sides(side):
+        if isinstance(side, (tuple, list)) and side[1] is not None:
+            K.wait_stream(side[0], side[1])
 
     def new_ctx(self):
         return Ctx(self.device)
@@ -545,6 +559,7 @@ class GeneratorEngine(_Engine):
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
                 K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], g_up[k + 1]], (B, h, w), self.ws)
         mid_level = self.grad_buckets()[1]
+        self._join_sides(side)
         if bucket_ready is not None:
             bucket_ready(0)
         # ---- encoder, innermost first
@@ -582,7 +597,9 @@ class GeneratorEngine(_Engine):
                     K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
             # (after this level's input gradient, the last reader of its weights: the caller may update the bucket now)
             if bucket_ready is not None and k == mid_level and k > 0:
+                self._join_sides(side)
                 bucket_ready(1)
+        self._join_sides(side)
         if bucket_ready is not None:
             bucket_ready(2 if mid_level > 0 else 1)
 

@@ -23,6 +23,7 @@ AUTO_GRAPH_PIXELS = 2 * 256 * 256      # use_graph="auto": hipGraph replay at or
 
 
 import os as _os
+WGRAD_STREAMS = int(_os.environ.get("PFA_WGRAD_STREAMS", "1"))
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
 
 
@@ -178,6 +179,8 @@ class GanTrainer:
         # second HIP stream: parameter-gradient kernels run under the dgrad/BatchNorm chain, D(real) under G forward
         self.side = torch.cuda.Stream(device=dev) if overlap else None
         self.side2 = torch.cuda.Stream(device=dev) if overlap else None
+        # optional fourth stream: the generator's weight gradients alternate between `side` and this one (PFA_WGRAD_STREAMS=2)
+        self.side3 = torch.cuda.Stream(device=dev) if overlap and WGRAD_STREAMS == 2 else None
         self._ev_real_fwd = torch.cuda.Event() if overlap else None
         self._ev_d_free = torch.cuda.Event() if overlap else None     # D engine idle, D weights final for this step
         self._d_free_recorded = False
@@ -301,7 +304,9 @@ class GanTrainer:
                 K.wait_stream(self.side, main)
                 with torch.cuda.stream(self.side):
                     self._works.append(self._reduce(garena[lo:hi], ("g", i), async_op=True))
-        G.backward(self.gctx, dpre, garena, side=self.side, bucket_ready=hook)
+        G.backward(self.gctx, dpre, garena,
+                   side=(self.side, self.side3) if self.side is not None and self.side3 is not None else self.side,
+                   bucket_ready=hook)
         if self.side is not None:
             K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:
