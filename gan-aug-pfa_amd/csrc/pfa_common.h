@@ -60,6 +60,11 @@ bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int
 size_t pfa_wgrad_patch_slab_floats(const pfa_wgrad_args* a, int slices);
 int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name);
 
+// csrc/wgrad_image.hip: weight gradient of the image-side layers (8-channel gathered operand)
+bool pfa_wgrad_image_plan(const pfa_wgrad_args* a, int* slices);
+size_t pfa_wgrad_image_slab_floats(const pfa_wgrad_args* a, int slices);
+int pfa_wgrad_image(const pfa_wgrad_args* a, hipStream_t st, const char** name);
+
 static inline int pfa_ch(int dtype) { return dtype == PFA_BF16 ? 8 : 4; }
 static inline int pfa_esize(int dtype) { return dtype == PFA_BF16 ? 2 : 4; }
 static inline int ilog2_exact(int v) {  // log2 if power of two else -1

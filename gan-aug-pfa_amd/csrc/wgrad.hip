@@ -505,6 +505,7 @@ extern "C" int pfa_wgrad_slices(const pfa_wgrad_args* a) {
     WgradK k; int msplit; bool small_i;
     if (int rc = wgrad_setup(a, k, msplit, small_i)) return rc < 0 ? rc : -rc;
     int ps;
+    if (pfa_wgrad_image_plan(a, &ps)) return ps;
     if (pfa_wgrad_patch_plan(a, &ps, nullptr, nullptr)) return ps;
     return msplit * k.kgroups;
 }
@@ -513,6 +514,7 @@ extern "C" size_t pfa_wgrad_slab_floats(const pfa_wgrad_args* a) {
     WgradK k; int msplit; bool small_i;
     if (wgrad_setup(a, k, msplit, small_i)) return 0;
     int ps;
+    if (pfa_wgrad_image_plan(a, &ps)) return pfa_wgrad_image_slab_floats(a, ps);
     if (pfa_wgrad_patch_plan(a, &ps, nullptr, nullptr)) return pfa_wgrad_patch_slab_floats(a, ps);
     const int bi = small_i ? 16 : (wgrad_ring(a, k) ? 256 : 128);
     return (size_t)msplit * ((k.jtot + 127) / 128) * ((k.dp + bi - 1) / bi) * bi * 128;
@@ -528,7 +530,10 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
     int rc;
     const char* name;
     int pslices = 0;
-    if (pfa_wgrad_patch_plan(a, &pslices, nullptr, nullptr)) {
+    if (a->slab && pfa_wgrad_image_plan(a, &pslices)) {
+        rc = pfa_wgrad_image(a, st, &name);
+        msplit = pslices;
+    } else if (pfa_wgrad_patch_plan(a, &pslices, nullptr, nullptr)) {
         rc = pfa_wgrad_patch(a, st, &name);
         msplit = pslices;
     } else if (a->dtype == PFA_BF16) {

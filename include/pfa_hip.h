@@ -69,7 +69,10 @@ uint64_t pfa_launch_count(void);
  * or slices K (0 = defaults); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
  * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half), 11..17 = diagnostic instantiations of the
- * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong. */
+ * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong;
+ * id 8: workgroups a weight-gradient patch launch wants (0 = 128); id 9: workgroup count from which transposed
+ * convolutions take four-class workgroups, id 10: 128-channel tile count below which stride-1 convolutions slice K (0 = 192); id 11: Adam grid (0 = default);
+ * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 128). */
 int pfa_set_knob(int id, int value);
 /* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write clock stamps per
  * workgroup: conv (uint64[workgroups][16]: 8 shader-clock stamps - entry, first fragments, K loop done, accumulators in LDS,

@@ -781,6 +781,69 @@ def test_convT_wgrad(case, dtype, ws):
         close(got, want, torch.float32, name)
 
 
+WGI_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels
+    ("e1_like", "conv", 4, [3], 32, 128, 64),              # dy 16 x 64: 4 x 2 tiles per image, one gathered source
+    ("c1_like", "conv", 2, [3, 3], 64, 128, 64),           # two gathered sources (A | B images)
+    ("d1_like", "convT", 4, [64, 64], 16, 64, 3),          # transposed: direct = the two 64-channel inputs, gathered = dy (3 ch)
+]
+
+
+def _last_wgrad_kernel(fn):
+    """Kernel name of the (first) weight-gradient launch fn() issues, from the library's timing store."""
+    import ctypes
+    lib = _lib.lib()
+    lib.pfa_gather_timing(1)
+    try:
+        fn()
+        torch.cuda.synchronize()
+        ms, name, flop, byts, sk = ctypes.c_float(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        assert lib.pfa_gather_timing_count() >= 1
+        _lib.check(lib.pfa_gather_timing_get(0, ctypes.byref(ms), ctypes.byref(name), ctypes.byref(flop), ctypes.byref(byts),
+                                             ctypes.byref(sk)), "pfa_gather_timing_get")
+        return name.value.decode()
+    finally:
+        lib.pfa_gather_timing(0)
+
+
+@pytest.mark.parametrize("case", WGI_CASES, ids=[c[0] for c in WGI_CASES])
+def test_wgrad_image_kernel(case, ws):
+    """Weight gradients of the image-side layers (models.py:183,184,223) on wgrad_image.hip: the oracle, and the general kernel
+    (pfa_set_knob(4, 9)) - one and two gathered sources, the transposed layer's two direct sources."""
+    name, kind, n, cins, h, w, co = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".wi.x", (n, ci, h, w)), dtype)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    if kind == "conv":
+        wt = fill.uniform(name + ".wi.w", (co, ci, 4, 4))
+        dy = rnd(fill.uniform(name + ".wi.dy", (n, co, h // 2, w // 2)), dtype)
+        _, want, _ = ops.conv2d_bwd(x, wt, dy, 2, need_dx=False)
+        shape, args = (co, 16, ci), lambda dw, dyt: ([dyt], srcs, dw, 2, [co], cins)
+    else:
+        wt = fill.uniform(name + ".wi.w", (ci, co, 4, 4))
+        dy = rnd(fill.uniform(name + ".wi.dy", (n, co, 2 * h, 2 * w)), dtype)
+        _, want, _ = ops.convT2d_bwd(x, wt, dy, need_dx=False)
+        shape, args = (ci, 16, co), lambda dw, dyt: (srcs, [dyt], dw, 2, cins, [co])
+    dyt = to_nhwc(dy, dtype)
+    res = []
+    for knob in (0, 9):
+        _lib.lib().pfa_set_knob(4, knob)
+        try:
+            for fresh in (True, False):
+                dw = torch.zeros(shape, dtype=torch.float32, device="cuda") if fresh else torch.full(shape, 0.5, dtype=torch.float32, device="cuda")
+                kern = _last_wgrad_kernel(lambda: K.wgrad(*args(dw, dyt), ws=ws, fresh=fresh))
+                assert kern.startswith("k_wgrad_image") == (knob == 0), kern
+                got = (dw if fresh else dw - 0.5).cpu().numpy().reshape(shape[0], 4, 4, shape[2]).transpose(0, 3, 1, 2)
+                close(got, want, torch.float32, f"{name} knob {knob} fresh {fresh}")
+                res.append(got)
+        finally:
+            _lib.lib().pfa_set_knob(4, 0)
+    close(res[0], res[2], torch.float32, name + " vs the general kernel")
+
+
 WGP_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels, stride, slab
     ("conv_s2_32", "conv", 2, [64], 64, 64, 128, 2, False),          # e2-like: dy 32x32, 2x32 tiles, atomics
     ("conv_s2_ragged", "conv", 1, [64], 40, 72, 128, 2, True),       # dy 20x36: ragged tile rows and columns, slab
