@@ -1215,7 +1215,8 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
                                    a->nb, a->hs, a->ws, a->c1, a->n, st);
         else
             rc = pfa_conv_s1_patch32(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, kk, pbn, a->hs, a->ws, a->c1, st);
-        g_last_gather_name = pbn == 128 ? "k_conv_s1_patch<bf16,8x32,128>" : "k_conv_s1_patch<bf16,8x32,64>";
+        g_last_gather_name = pbn != 128 ? "k_conv_s1_patch<bf16,8x32,64>"
+                             : pfa_knob(3) == 6 || pfa_knob(3) == 8 ? "k_conv_s1_patch<bf16,8x32,128>" : "k_conv_s1_inplace<bf16,8x32,128>";
     } else if (image) {
         const char* nm = "";
         rc = pfa_conv_image(kk, st, &nm);

@@ -237,7 +237,7 @@ bool pfa_wgrad_image_plan(const pfa_wgrad_args* a, int* slices) {
     if ((long long)a->nb * a->hg * a->wg * 16 >= (1ll << 31) || (long long)a->nb * a->hq * a->wq * cd * 2 >= (1ll << 31)) return false;
     const int ntiles = a->nb * (a->hq / GTY) * (a->wq / GTX);
     if (ntiles < 32) return false;
-    const int want = pfa_knob(12) > 0 ? pfa_knob(12) : 128;               // workgroups a launch aims for (knob 12)
+    const int want = pfa_knob(12) > 0 ? pfa_knob(12) : 256;               // workgroups a launch aims for (knob 12)
     int s = ntiles < want ? ntiles : want;
     const int sper = (ntiles + s - 1) / s;
     s = (ntiles + sper - 1) / sper;

@@ -24,6 +24,7 @@ AUTO_GRAPH_PIXELS = 2 * 256 * 256      # use_graph="auto": hipGraph replay at or
 
 import os as _os
 WGRAD_STREAMS = int(_os.environ.get("PFA_WGRAD_STREAMS", "1"))
+D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s weight gradients alternate between side2 and side
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
 
 
@@ -185,6 +186,7 @@ class GanTrainer:
         self._ev_d_free = torch.cuda.Event() if overlap else None     # D engine idle, D weights final for this step
         self._d_free_recorded = False
         self.inputs_resident = bool(inputs_resident)
+        self.marks = None
         self._loss_real = torch.zeros(1, dtype=torch.float32, device=dev)
         self._graphs = None
         self._listing = False          # launch lists are being warmed up / recorded / replayed (use_graph == "replay")
@@ -195,6 +197,13 @@ class GanTrainer:
         self.Dn.refresh_shadows(force=True)
 
     # ----------------------------------------------------------------------------------- pieces of a step
+    def _mark(self, name, stream=None):
+        """Developer timing (tools/step_marks.py): with self.marks a list, a timing event on `stream` at this point."""
+        if self.marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self.marks.append((name, ev))
+
     def _d_phase(self, xa, xb, graph_safe, ready=None):
         G, Dn = self.G, self.Dn
         K.fill_zero(self.losses)
@@ -231,29 +240,39 @@ class GanTrainer:
                 K.wait_event(self.side, ready)
         else:
             K.wait_stream(self.side, main)
+        self._mark("step", main)
         K.fill_zero(garena)
         with torch.cuda.stream(self.side):
+            self._mark("side: D(real) begins")
             K.fill_zero(garena2)
             K.fill_zero(self._loss_real)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
             K.bce_logits(lr, 1.0, 0.5, 0.5, self._loss_real, dl_r)
             K.record_event(self._ev_real_fwd, self.side)
+            self._mark("side: D(real) forward done")
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True)
+            self._mark("side: D(real) backward done")
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
+        self._mark("G forward done")
         K.wait_event(main, self._ev_real_fwd)
         lf = Dn.forward([xa, fake], self.ctx_f, train=True)
         dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
         K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
-        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=self.side2)
+        self._mark("D(fake) forward done")
+        # (side is free again: D(real) finished under the generator's forward)
+        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2)
+        self._mark("D(fake) backward chain done")
         K.wait_stream(main, self.side)
         K.wait_stream(main, self.side2)
+        self._mark("D gradients complete")
         K.axpy(self.losses[0:1], self._loss_real)
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
         self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=self.side is not None)
         Dn.refresh_shadows(force=True)
+        self._mark("Adam(D) done")
         self.opt_g.zero_grad()
         fake = self.gctx.v["fake"]
         lg = Dn.forward([xa, fake], self.ctx_r, train=True)
@@ -263,6 +282,7 @@ class GanTrainer:
         if self._ev_d_free is not None and (not graph_safe or self._listing):
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
+        self._mark("G phase: D forward + input gradient done")
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
         K.l1_tanh_bwd(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self.losses[1:2], dpre)
         garena = self.opt_g.flat().grad
@@ -307,11 +327,13 @@ class GanTrainer:
         G.backward(self.gctx, dpre, garena,
                    side=(self.side, self.side3) if self.side is not None and self.side3 is not None else self.side,
                    bucket_ready=hook)
+        self._mark("G backward chain done")
         if self.side is not None:
             K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:
             K.wait_stream(torch.cuda.current_stream(), self.side2)
             G.shadows_refreshed()
+        self._mark("G gradients (and bucketed Adam) complete")
         for w in self._works:
             w.wait()                 # the current stream waits for the collective; no host sync
         self._g_reduced = hook is not None
