@@ -128,7 +128,7 @@ int launch_image(const ImageK& k, hipStream_t st) {
     constexpr int IN_BYTES = NSRC * PATCH_BYTES + 64 * K * 2;
     constexpr int OUT_BYTES = 256 * patch_image_stride<64>();
     constexpr int LDS = IN_BYTES > OUT_BYTES ? IN_BYTES : OUT_BYTES;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_image<NSRC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;

@@ -16,6 +16,7 @@
 //                  taps and 16 pixels (loaded once, all in flight); a block = 4 input rows of one image reduces in LDS and
 //                  meets the other blocks in float atomics on whole rows of dw.
 #include "pfa_common.h"
+#include <atomic>
 
 namespace {
 
@@ -331,7 +332,7 @@ extern "C" int pfa_logit_fwd(const void* x, const void* w, const float* bias, vo
     k.x = (const char*)x; k.wt = (const bf16_t*)w; k.bias = bias; k.out = (char*)logits;
     k.xtiles = (wd - 1 + FT - 1) / FT;
     constexpr int LDS = 4 * FPW * 1024;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         const hipError_t e = hipFuncSetAttribute((const void*)k_logit_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         PFA_REQUIRE(e == hipSuccess, "pfa_logit_fwd: %s", hipGetErrorString(e));

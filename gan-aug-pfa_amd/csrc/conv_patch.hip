@@ -630,7 +630,7 @@ int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float
     k.splitk = splitk; k.cper = cin / 64 / splitk;
     k.tiles_y = (k.hout + TY - 1) / TY; k.tiles_x = (k.wout + TX - 1) / TX; k.ntiles = n / 128;
     k.nwg = nb * k.tiles_y * k.tiles_x * k.ntiles * splitk;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_s1_patch, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
@@ -675,7 +675,7 @@ static int launch_s1_patch32(const Patch32K& q, hipStream_t st) {
     constexpr int LOOP_BYTES = 2 * PATCH_BYTES + 3 * BN * 128, OUT_BYTES = 256 * patch_image_stride<BN>();
     constexpr int LDS = LOOP_BYTES > OUT_BYTES ? LOOP_BYTES : OUT_BYTES;
     static_assert(LDS <= 163840, "LDS");
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_s1_patch32<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
@@ -696,7 +696,7 @@ int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, in
     q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / bn;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
     if (bn == 128 && pfa_knob(3) != 8) {                     // knob 3 = 8: the two-phase loop (A/B)
-        static bool attr_done = false;
+        static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)k_conv_s1_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_done = true;

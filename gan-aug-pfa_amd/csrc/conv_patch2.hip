@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 template <int MODE, int BN, int TILE16, int ABL = 0>
 int launch_patch2(const Patch2K& k, hipStream_t st) {
     constexpr int LDS = 2 * PATCH_BYTES + W_SLOTS * BN * 128;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_conv_patch2<MODE, BN, TILE16, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;

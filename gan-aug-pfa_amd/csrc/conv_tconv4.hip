@@ -240,7 +240,7 @@ int pfa_tconv4(const GatherK& k, int tiles_y, int tiles_x, hipStream_t st, const
     q.nwg = k.nb * tiles_y * tiles_x * q.ntiles;
     q.nchunks = k.ctot / 64; q.c1chunks = k.c1 / 64;
     constexpr int LDS = T4_LDS_LOOP > 256 * patch_image_stride<T4_BN>() ? T4_LDS_LOOP : 256 * patch_image_stride<T4_BN>();
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_tconv4, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;

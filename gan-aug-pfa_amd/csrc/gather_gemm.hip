@@ -1040,7 +1040,7 @@ static int launch_gather(GatherK k, int classes, hipStream_t st) {
     k.order = choose_order(k);
     dim3 grid(k.nwg);
     const size_t lds = (EARLY >= 3 ? 3 : 2) * (BM * 128 + BN * 128);
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_gather_gemm<T, BM, BN, WM, WN, EARLY>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

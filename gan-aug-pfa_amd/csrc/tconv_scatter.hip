@@ -16,6 +16,7 @@
 // The input is read ~1.4x (halo) instead of 16x; results do not depend on the tiling (each output's four terms are
 // summed in a fixed order: ky ascending, kx ascending).
 #include "pfa_common.h"
+#include <atomic>
 
 namespace {
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
 template <typename T, int NCO>
 int launch_scatter(const ScatterK& k, hipStream_t st) {
     constexpr int lds = scatter_lds_bytes<NCO>();
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_tconv_scatter<T, NCO>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;

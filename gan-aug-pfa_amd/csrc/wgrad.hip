@@ -16,6 +16,7 @@
 // hardware transpose read ds_read_b64_tr_b16 (bf16) / plain ds_read_b32 (f32, one value per lane).
 // The reduction is sliced over blockIdx.z; slices combine with float32 atomics (dw is pre-zeroed).
 #include "pfa_common.h"
+#include <atomic>
 
 constexpr int WGRAD_DEFAULT_EARLY = 0;
 
@@ -419,7 +420,7 @@ int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     k.itiles = (k.dp + BI - 1) / BI;
     k.nwg = k.jtiles * k.itiles * msplit;
     dim3 grid(k.nwg);
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);

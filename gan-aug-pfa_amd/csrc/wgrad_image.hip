@@ -14,6 +14,7 @@
 // channels; the 2-8 (row tile, column tile) pairs of the [CD][128 | 256] output are dealt to the 8 waves.  Partial tiles of the
 // slices go to a slab, a second kernel adds them in slice order and stores the real channels (bitwise reproducible).
 #include "pfa_common.h"
+#include <atomic>
 
 namespace {
 
@@ -121,11 +122,9 @@ __global__ __launch_bounds__(512) void k_wgrad_image(const WgiK p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
 
-    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
     auto tr = [&](unsigned addr) -> bf16x4 {
-        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(smem + (addr - 0)));
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(smem + addr));
     };
-    (void)lds0;
 
     if (t0 < t1) stage(t0, 0);
     if (NSTG == 3 && t0 + 1 < t1) stage(t0 + 1, 1);
@@ -213,7 +212,7 @@ int launch_wgi(const WgiK& k, hipStream_t st) {
     constexpr int STAGE = GPOS * CD * 2 + NG * GPATCH;
     constexpr int LDS = (3 * STAGE <= 163840 ? 3 : 2) * STAGE;
     static_assert(LDS <= 163840, "LDS");
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_wgrad_image<CD, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;

@@ -21,6 +21,7 @@
 // vmcnt), fragments read IN PLACE two k-steps (2 x 16 pixels) ahead of their MFMAs - the LDS queue holds 15 reads - and
 // every LDS address is a per-lane register plus an immediate (the loop is unrolled over the 4 stages).
 #include "pfa_common.h"
+#include <atomic>
 
 #include <type_traits>
 
@@ -342,7 +343,7 @@ int launch_wgp(const WgpK& k, hipStream_t st) {
     constexpr int RP = ((STRIDE == 1 ? PLW : 2 * PLW) + 3) & ~3;
     constexpr int PP = (TY * RP * 8 + 511) / 512;
     constexpr int LDS = NSTAGE * (DIR_BYTES + PP * 8192);
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)k_wgrad_patch<STRIDE, TX, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;

@@ -25,6 +25,7 @@ AUTO_GRAPH_PIXELS = 2 * 256 * 256      # use_graph="auto": hipGraph replay at or
 import os as _os
 WGRAD_STREAMS = int(_os.environ.get("PFA_WGRAD_STREAMS", "1"))
 D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s weight gradients alternate between side2 and side
+DREAL_WGRAD_SIDE = _os.environ.get("PFA_DREAL_WGRAD_SIDE", "0") != "0"   # D(real)'s weight gradients on side2 instead of in line
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
 
 
@@ -251,7 +252,7 @@ class GanTrainer:
             K.bce_logits(lr, 1.0, 0.5, 0.5, self._loss_real, dl_r)
             K.record_event(self._ev_real_fwd, self.side)
             self._mark("side: D(real) forward done")
-            Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True)
+            Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True, side=self.side2 if DREAL_WGRAD_SIDE else None)
             self._mark("side: D(real) backward done")
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
         self._mark("G forward done")
