@@ -26,8 +26,11 @@ def display(name):
         return "k_conv_s1_patch<bf16,8x32,128>"
     if "k_tconv4" in name:
         return "k_tconv4<64,8x32>"
-    if "k_wgrad_patch_reduce" in name or "k_wgrad_reduce" in name:
+    if "k_wgrad_patch_reduce" in name or "k_wgrad_reduce" in name or "k_wgrad_image_reduce" in name:
         return None
+    if "k_wgrad_image" in name:
+        a = [int(x) for x in re.findall(r"(?:Li|<|, ?)(\d+)", name.split("k_wgrad_image")[1][:20])[:2]]
+        return f"k_wgrad_image<{a[0]},{'2x8ch' if a[1] == 2 else '8ch'}>"
     if "k_wgrad_patch" in name:
         a = [int(x) for x in re.findall(r"(?:Li|<|, ?)(\d+)", name.split("k_wgrad_patch")[1][:30])[:2]]
         return f"k_wgrad_patch<s{a[0]},{'2x32' if a[1] == 32 else '4x16'}>"
