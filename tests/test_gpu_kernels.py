@@ -781,10 +781,13 @@ def test_convT_wgrad(case, dtype, ws):
         close(got, want, torch.float32, name)
 
 
-WGI_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels
-    ("e1_like", "conv", 4, [3], 32, 128, 64),              # dy 16 x 64: 4 x 2 tiles per image, one gathered source
-    ("c1_like", "conv", 2, [3, 3], 64, 128, 64),           # two gathered sources (A | B images)
-    ("d1_like", "convT", 4, [64, 64], 16, 64, 3),          # transposed: direct = the two 64-channel inputs, gathered = dy (3 ch)
+WGI_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels, slices wanted (knob 12; 0 = default)
+    ("e1_like", "conv", 4, [3], 32, 128, 64, 0),           # dy 16 x 64: 4 x 2 tiles per image, one gathered source
+    ("c1_like", "conv", 2, [3, 3], 64, 128, 64, 0),        # two gathered sources (A | B images)
+    ("d1_like", "convT", 4, [64, 64], 16, 64, 3, 0),       # transposed: direct = the two 64-channel inputs, gathered = dy (3 ch)
+    ("e1_runs", "conv", 5, [3], 32, 128, 64, 16),          # 40 tiles in 14 slices: runs of 3 tiles through the ring, the last slice 1 tile
+    ("e1_pairs", "conv", 4, [3], 32, 128, 64, 16),         # 32 tiles in 16 slices of 2: the ring never fills
+    ("c1_wide", "conv", 4, [3, 3], 32, 128, 128, 0),       # 128 direct channels x two gathered sources: the two-stage instantiation
 ]
 
 
@@ -809,7 +812,7 @@ def _last_wgrad_kernel(fn):
 def test_wgrad_image_kernel(case, ws):
     """Weight gradients of the image-side layers (models.py:183,184,223) on wgrad_image.hip: the oracle, and the general kernel
     (pfa_set_knob(4, 9)) - one and two gathered sources, the transposed layer's two direct sources."""
-    name, kind, n, cins, h, w, co = case
+    name, kind, n, cins, h, w, co, want_slices = case
     dtype = torch.bfloat16
     ci = sum(cins)
     x = rnd(fill.uniform(name + ".wi.x", (n, ci, h, w)), dtype)
@@ -831,6 +834,7 @@ def test_wgrad_image_kernel(case, ws):
     res = []
     for knob in (0, 9):
         _lib.lib().pfa_set_knob(4, knob)
+        _lib.lib().pfa_set_knob(12, want_slices)
         try:
             for fresh in (True, False):
                 dw = torch.zeros(shape, dtype=torch.float32, device="cuda") if fresh else torch.full(shape, 0.5, dtype=torch.float32, device="cuda")
@@ -841,7 +845,20 @@ def test_wgrad_image_kernel(case, ws):
                 res.append(got)
         finally:
             _lib.lib().pfa_set_knob(4, 0)
+            _lib.lib().pfa_set_knob(12, 0)
     close(res[0], res[2], torch.float32, name + " vs the general kernel")
+    # slab + ordered reduce: the same bits on every run
+    _lib.lib().pfa_set_knob(12, want_slices)
+    try:
+        runs = []
+        for _ in range(3):
+            dw = torch.zeros(shape, dtype=torch.float32, device="cuda")
+            K.wgrad(*args(dw, dyt), ws=ws, fresh=True)
+            runs.append(dw.clone())
+    finally:
+        _lib.lib().pfa_set_knob(12, 0)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), name + ": not reproducible"
+    assert np.array_equal(runs[0].cpu().numpy().reshape(shape[0], 4, 4, shape[2]).transpose(0, 3, 1, 2), res[0]), name
 
 
 WGP_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels, stride, slab
