@@ -52,21 +52,32 @@ template <int OFF> __device__ __forceinline__ void tr_rd(unsigned addr, bf16x4& 
 }
 template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("" : "+v"(v)); }
 
-constexpr int NSTAGE = 4;
 constexpr int DIR_BYTES = 64 * 256;
+constexpr int wgp_stages(int stage_bytes) { return 4 * stage_bytes <= 163840 ? 4 : 3; }
 
 // STRIDE 1 | 2; TX 32 (2 x 32 positions per step) | 16 (4 x 16)
 // ABL: ablation bits of a diagnostic instantiation (1 no MFMA, 2 no fragment reads, 4 no DMA - results are wrong)
-template <int STRIDE, int TX, int ABL = 0>
+// NKY: tap rows per workgroup.  2: the pair (ky0, ky0 + KYD) with KYD = 1 at stride 1, 2 at stride 2 - the second row's
+// gathered pixels are the first's one patch row further down, so the patch grows by ONE row (TY + 1 instead of 2 TY), the
+// direct tile and its fragments serve both rows, and a step carries twice the MFMAs for 6 instead of 2 x 5 DMA instructions;
+// three ring stages of 48 KiB instead of four of 40.
+template <int STRIDE, int TX, int ABL = 0, int NKY = 1>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad_patch(const WgpK p) {
     constexpr bool no_mfma = ABL & 1, no_read = ABL & 2, no_dma = ABL & 4;
+    constexpr int KYG = 4 / NKY, KYD = STRIDE == 1 ? 1 : 2;               // tap-row groups; distance of a group's two rows
     constexpr int TY = 64 / TX;
     constexpr int PLW = STRIDE == 1 ? TX + 3 : TX + 1;                    // pixels of a patch row (per plane at stride 2)
     constexpr int RP = ((STRIDE == 1 ? PLW : 2 * PLW) + 3) & ~3;          // row pitch in pixel slots, a multiple of 4
-    constexpr int PSLOTS = TY * RP;
+    constexpr int PSLOTS = (TY + NKY - 1) * RP;
     constexpr int PP = (PSLOTS * 8 + 511) / 512;                          // DMA passes of the patch
     constexpr int PATCH_BYTES = PP * 8192;
     constexpr int STAGE = DIR_BYTES + PATCH_BYTES;
+    // Ring: four stages where they fit - one barrier at the top of a step, the stage three steps ahead issued over its four
+    // k-steps.  Three stages (two tap rows at stride 2 on the 2 x 32 tile: 48 KiB each): the barrier sits in the MIDDLE of
+    // the step - behind it every wave has left stage i-1 (its last fragments went into the MFMAs of the step before) and
+    // stage i+1 has landed (vmcnt(0) in front of the barrier) - and the second half of the step issues stage i+2 into the slot
+    // of stage i-1 and reads ahead into stage i+1.
+    constexpr int NSTAGE = wgp_stages(STAGE);
     constexpr int NOPS = 2 + PP;                                          // DMA instructions per wave and step (at most)
     // the last patch pass covers PSLOTS * 8 - (PP - 1) * 512 lanes: only its first LASTW waves issue it (the DMA is priced per
     // instruction: on 7 of 8 waves one of 4-5 instructions per step disappears)
@@ -81,7 +92,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     // work list: (c tile, ky, i tile) fastest - the workgroups of one pixel slice share both operands' pixels - then slice
     unsigned wid = xcd_remap(blockIdx.x, p.nwg);
     const int ct = wid % p.ctiles; wid /= p.ctiles;
-    const int ky = wid & 3; wid >>= 2;
+    const int kg = wid % KYG; wid /= KYG;
+    const int ky = NKY == 1 ? kg : (STRIDE == 1 ? 2 * kg : kg);          // (first) tap row of this workgroup
     const int it = wid % p.itiles;
     const int split = wid / p.itiles;
     const int i0 = it * 128, c0 = ct * 64;
@@ -93,8 +105,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     const int step0 = split * p.sper;
     const int nlive = min(p.nsteps, step0 + p.sper) - step0;       // real steps of this slice
-    const int nsteps = (nlive + 3) & ~3;                           // the loop runs whole groups of four: the (at most three) extra
-                                                                   // steps of the last slice stage zeros and add nothing
+    const int nsteps = (nlive + NSTAGE - 1) / NSTAGE * NSTAGE;     // the loop runs whole turns of the ring: the extra steps of the
+                                                                   // last slice stage zeros and add nothing
 
     // ---- DMA roles.  Direct tile: 2 pieces; lane -> (pixel, chunk position).  Edge flags: 1 = beyond the right edge in the
     // last tile column, 2 = beyond the bottom edge in the last tile row, 4 = left of the image in the first column,
@@ -172,25 +184,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         if (++d_tx == p.tiles_x) { d_tx = 0; if (++d_ty == p.tiles_y) { d_ty = 0; ++d_img; } }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NKY][2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int y = 0; y < NKY; ++y)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[y][a][b][e] = 0.f;
 
     // ---- fragment addresses (ds_read_b64_tr_b16: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3 of the
     // group's 4 x 16 block; 32x32x16 operands: lanes 0-15 / 16-31 = rows 0-15 / 16-31 of the tile, lanes 32-63 the second
     // 8 k of the 16)
     const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
     const int grp = lane >> 4, cb = 16 * (grp & 1), lh = grp >> 1, rq = (lane & 15) >> 2, pp4 = (lane & 3) * 4;
-    unsigned aadr[2][2], badr[2][2];     // [tile][ring slots 0,1 | 2,3]: the ds offset field holds 16 bits
+    unsigned aadr[2][NSTAGE], badr[2][NSTAGE];     // [tile][ring slot]: the ds offset field holds 16 bits
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int ch = wi * 64 + a * 32 + cb + pp4, px = 8 * lh + rq;
         aadr[a][0] = lds0 + px * 256 + ((((ch >> 3) ^ (rq << 2)) & 15) << 4) + (ch & 7) * 2;
-        aadr[a][1] = aadr[a][0] + 2 * STAGE;
+#pragma unroll
+        for (int sl = 1; sl < NSTAGE; ++sl) aadr[a][sl] = aadr[a][0] + sl * STAGE;
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -198,36 +213,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int tap = STRIDE == 1 ? kx : ((kx & 1) ? PLW : 0) + (kx >> 1);       // stride 2: kx odd -> even-column plane
         const int slot = 8 * lh + rq + tap;                                          // + the (k-step, half) part below
         badr[b][0] = lds0 + DIR_BYTES + slot * 128 + ((((ch >> 3) ^ (((slot >> 1) & 1) << 2)) & 7) << 4) + (ch & 7) * 2;
-        badr[b][1] = badr[b][0] + 2 * STAGE;
+#pragma unroll
+        for (int sl = 1; sl < NSTAGE; ++sl) badr[b][sl] = badr[b][0] + sl * STAGE;
     }
     // immediate of (k-step s, half e): direct rows 16 s + 4 e; patch slots of pixel 16 s + 4 e of the step
     // fragments of two k-steps (parity of the k-step index)
-    bf16x4 fa[2][2][2], fb[2][2][2];          // [set][tile][half]
+    bf16x4 fa[2][2][2], fb[2][NKY][2][2];     // [set][tile][half], [set][tap row][tile][half]
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) { fa[s][t][e] = bf16x4{}; fb[s][t][e] = bf16x4{}; }
+            for (int e = 0; e < 2; ++e) {
+                fa[s][t][e] = bf16x4{};
+#pragma unroll
+                for (int y = 0; y < NKY; ++y) fb[s][y][t][e] = bf16x4{};
+            }
+    constexpr int NR = 4 + 4 * NKY;           // fragment reads of a k-step
     auto read_kstep = [&](auto slot_, auto s_) {             // the 8 reads of k-step S of the stage in ring slot SL
         if (no_read) return;
         constexpr int SL = decltype(slot_)::value, S = decltype(s_)::value, SET = S & 1;
         constexpr int ppix = TX == 32 ? (S >> 1) * RP + 16 * (S & 1) : S * RP;      // first pixel slot of the k-step's rows
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            tr_rd<(SL & 1) * STAGE + (16 * S) * 256>(aadr[a][SL >> 1], fa[SET][a][0]);
-            tr_rd<(SL & 1) * STAGE + (16 * S + 4) * 256>(aadr[a][SL >> 1], fa[SET][a][1]);
+            tr_rd<(16 * S) * 256>(aadr[a][SL], fa[SET][a][0]);
+            tr_rd<(16 * S + 4) * 256>(aadr[a][SL], fa[SET][a][1]);
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            tr_rd<(SL & 1) * STAGE + ppix * 128>(badr[b][SL >> 1], fb[SET][b][0]);
-            tr_rd<(SL & 1) * STAGE + (ppix + 4) * 128>(badr[b][SL >> 1], fb[SET][b][1]);
-        }
+        for (int y = 0; y < NKY; ++y)          // (the second tap row: the same pixels one patch row further down)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (y == 0) {
+                    tr_rd<ppix * 128>(badr[b][SL], fb[SET][0][b][0]);
+                    tr_rd<(ppix + 4) * 128>(badr[b][SL], fb[SET][0][b][1]);
+                } else {
+                    tr_rd<(ppix + RP) * 128>(badr[b][SL], fb[SET][NKY - 1][b][0]);
+                    tr_rd<(ppix + RP + 4) * 128>(badr[b][SL], fb[SET][NKY - 1][b][1]);
+                }
+            }
     };
 
-    // ---- prologue: stages 0..2, the fragments of k-steps 0 and 1 of stage 0
+    // ---- prologue: stages 0..NSTAGE-2, the fragments of k-steps 0 and 1 of stage 0
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < NSTAGE - 1; ++s)
         if (s < nsteps) { stage(s, 0, NOPS); advance(); }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
@@ -237,69 +265,94 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     // one step on ring slot SL; more: a step follows
     auto body = [&](int i, auto slot_, const bool more) {
-        constexpr int SL = decltype(slot_)::value, NSL = (SL + 1) & 3, DSL = (SL + 3) & 3;
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const bool issue = i + 3 < nsteps;                   // stage i+3 into the slot stage i-1 has left
+        constexpr int SL = decltype(slot_)::value, NSL = (SL + 1) % NSTAGE, DSL = (SL + NSTAGE - 1) % NSTAGE;
+        if constexpr (NSTAGE == 4) {
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool issue = i + NSTAGE - 1 < nsteps;          // the stage NSTAGE-1 ahead into the slot stage i-1 has left
         auto kstep = [&](auto s_) {
             constexpr int S = decltype(s_)::value, SET = S & 1;
             // fragments of this k-step have landed: the reads issued after them are those of the next k-step (8), if any
-            if (!no_read) { if (S < 3 || more) wait_lgkm<8>(); else wait_lgkm<0>(); }
+            if (!no_read) { if (S < 3 || more) wait_lgkm<NR>(); else wait_lgkm<0>(); }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) { pin(fa[SET][t][e]); pin(fb[SET][t][e]); }
+                for (int e = 0; e < 2; ++e) {
+                    pin(fa[SET][t][e]);
+#pragma unroll
+                    for (int y = 0; y < NKY; ++y) pin(fb[SET][y][t][e]);
+                }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 const bf16x8 av = __builtin_shufflevector(fa[SET][a][0], fa[SET][a][1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const bf16x8 bv = __builtin_shufflevector(fb[SET][b][0], fb[SET][b][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (!no_mfma) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[a][b], 0, 0, 0);
-                }
+                for (int y = 0; y < NKY; ++y)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const bf16x8 bv = __builtin_shufflevector(fb[SET][y][b][0], fb[SET][y][b][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        if (!no_mfma) acc[y][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[y][a][b], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);
             // two k-steps ahead, into the registers just consumed
             if constexpr (S < 2) read_kstep(slot_, std::integral_constant<int, S + 2>{});
             else if (more) read_kstep(std::integral_constant<int, NSL>{}, std::integral_constant<int, S - 2>{});
-            // this step's DMA, spread over the k-steps
-            if (issue) stage(DSL, (S * NOPS) / 4, ((S + 1) * NOPS) / 4);
+            // this step's DMA, spread over the k-steps (three stages: over the two behind the barrier)
+            if (issue) {
+                if constexpr (NSTAGE == 4) stage(DSL, (S * NOPS) / 4, ((S + 1) * NOPS) / 4);
+                else if constexpr (S >= 2) stage(DSL, ((S - 2) * NOPS) / 2, ((S - 1) * NOPS) / 2);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
+        if constexpr (NSTAGE == 3) {
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
-        if (issue) {
-            advance();
-            if (no_dma) wait_vm<0>();
-            else if (last_pass) wait_vm<NOPS>();
-            else wait_vm<NOPS - 1>();
-        } else wait_vm<0>();
+        if constexpr (NSTAGE == 4) {
+            if (issue) {
+                advance();
+                if (no_dma) wait_vm<0>();
+                else if (last_pass) wait_vm<NOPS>();
+                else wait_vm<NOPS - 1>();
+            } else wait_vm<0>();
+        } else if (issue) advance();
     };
-    for (int i = 0; i < nsteps; i += 4) {
+    for (int i = 0; i < nsteps; i += NSTAGE) {
         body(i, std::integral_constant<int, 0>{}, true);
         body(i + 1, std::integral_constant<int, 1>{}, true);
-        body(i + 2, std::integral_constant<int, 2>{}, true);
-        body(i + 3, std::integral_constant<int, 3>{}, i + 4 < nsteps);
+        if constexpr (NSTAGE == 4) {
+            body(i + 2, std::integral_constant<int, 2>{}, true);
+            body(i + 3, std::integral_constant<int, 3>{}, i + 4 < nsteps);
+        } else {
+            body(i + 2, std::integral_constant<int, 2>{}, i + 3 < nsteps);
+        }
     }
 
     stamp(2);
     // ---- epilogue: lane holds D[i = 8 g + 4 lh' + r][c = lane & 31] of tile (a, b): rows = direct channels, columns = gathered
     const int col = lane & 31, rh = lane >> 5;
-    const int tile = (it * 4 + ky) * p.ctiles + ct;
     if (p.slab) {
-        float* dst = p.slab + ((size_t)split * (p.itiles * 4 * p.ctiles) + tile) * (128 * 4 * 64);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int y = 0; y < NKY; ++y) {
+            const int tile = (it * 4 + ky + y * KYD) * p.ctiles + ct;
+            float* dst = p.slab + ((size_t)split * (p.itiles * 4 * p.ctiles) + tile) * (128 * 4 * 64);
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
-                    dst[(i * 4 + kx) * 64 + b * 32 + col] = acc[a][b][e];
-                }
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+                        dst[(i * 4 + kx) * 64 + b * 32 + col] = acc[y][a][b][e];
+                    }
+        }
         if (p.stamps) {
             __builtin_amdgcn_s_waitcnt(0);
             stamp(3);
@@ -308,14 +361,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         return;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int y = 0; y < NKY; ++y)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
-                atomicAdd(p.dw + ((size_t)i * 16 + ky * 4 + kx) * p.gp + c0 + b * 32 + col, acc[a][b][e]);
-            }
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + wi * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * rh;
+                    atomicAdd(p.dw + ((size_t)i * 16 + (ky + y * KYD) * 4 + kx) * p.gp + c0 + b * 32 + col, acc[y][a][b][e]);
+                }
 }
 
 // dw[i][tap][c] += sum over slices of the partial tiles, slices in ascending order (bitwise reproducible).
@@ -336,19 +391,20 @@ __global__ __launch_bounds__(256) void k_wgrad_patch_reduce(const WgpK p) {
     else *(f32x4*)dst = *(const f32x4*)dst + s;
 }
 
-template <int STRIDE, int TX, int ABL = 0>
+template <int STRIDE, int TX, int ABL = 0, int NKY = 1>
 int launch_wgp(const WgpK& k, hipStream_t st) {
     constexpr int TY = 64 / TX;
     constexpr int PLW = STRIDE == 1 ? TX + 3 : TX + 1;
     constexpr int RP = ((STRIDE == 1 ? PLW : 2 * PLW) + 3) & ~3;
-    constexpr int PP = (TY * RP * 8 + 511) / 512;
-    constexpr int LDS = NSTAGE * (DIR_BYTES + PP * 8192);
+    constexpr int PP = ((TY + NKY - 1) * RP * 8 + 511) / 512;
+    constexpr int STAGE = DIR_BYTES + PP * 8192;
+    constexpr int LDS = wgp_stages(STAGE) * STAGE;
     static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad_patch<STRIDE, TX, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)k_wgrad_patch<STRIDE, TX, ABL, NKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_wgrad_patch<STRIDE, TX, ABL>), dim3(k.nwg), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL((k_wgrad_patch<STRIDE, TX, ABL, NKY>), dim3(k.nwg), dim3(512), LDS, st, k);
     PFA_LAUNCHED("k_wgrad_patch");
     return 0;
 }
@@ -358,6 +414,18 @@ int launch_wgp(const WgpK& k, hipStream_t st) {
 // The launches the patch kernel takes: bf16, direct channels in whole 128-tiles per source, ONE gathered source in whole
 // 64-tiles, no pad channels on either side, a direct map at least 16 wide and 64 positions large, tensors below 2 GiB.
 // Reduction slices: enough for ~256 workgroups, at least 4 steps each.  pfa_set_knob(4, 7) turns the route off.
+// Tap rows per workgroup: 1; 2 with pfa_set_knob(13, 2).  Two rows cut the LDS-DMA instructions per MFMA by 40 % and the
+// fragment reads by 25 %, and a launch of the same workgroup count has twice the slices.  Alone, c4 goes 125 -> 106 us and
+// e4 / d4 49 / 78 -> 43 / 74 us (four-stage ring); on the 2 x 32 tile at stride 2 (three stages, barrier in mid-step) the
+// step's DMA and MFMAs hardly overlap (3700 cycles per double step against 2330 + 1980 alone) and nothing is gained.
+// Inside the training step: 3.15 ms against 3.13 (knob 13 = 2), 3.13 against 3.14 (knob 13 = 3) - the partial tiles of
+// the extra slices cost what the loop saves, so one row stays the default.
+// knob 13 = 3: two rows where the ring keeps four stages (stride 1, and the 4 x 16 tile at stride 2)
+static int pfa_wgrad_patch_nky(int stride, int tx) {
+    const int k = pfa_knob(13);
+    return k == 2 ? 2 : k == 3 ? (stride == 1 || tx == 16 ? 2 : 1) : 1;
+}
+
 bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int* steps_out) {
     const int k4 = pfa_knob(4);
     if (k4 == 7 || k4 == 1 || k4 == 2 || k4 == 3) return false;              // explicit old-kernel variants / route off
@@ -370,18 +438,20 @@ bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int
     if (dbytes >= (1ll << 31) || gbytes >= (1ll << 31)) return false;
     const int tx = a->wq >= 24 ? 32 : 16, ty = 64 / tx;
     const int steps = a->nb * ((a->hq + ty - 1) / ty) * ((a->wq + tx - 1) / tx);
-    const int tiles = ((a->d1p + a->d2p) / 128) * 4 * (a->g1p / 64);
+    const int tiles = ((a->d1p + a->d2p) / 128) * 4 * (a->g1p / 64);           // output tiles
+    const int nky = pfa_wgrad_patch_nky(a->stride, tx);
+    const int wgs = tiles / nky;                                                // workgroups of one reduction slice
     // workgroups a launch aims for (knob 8).  In-situ sweep: 512 -> 3.39 ms per step, 256 -> 3.35, 192 -> 3.30, 128 -> 3.28,
     // 96 -> 3.30, 64 -> 3.36: these launches share the GPU with the main stream, and fewer slices are fewer partial tiles
     const int want = pfa_knob(8) > 0 ? pfa_knob(8) : 128;
-    int ms = (want + tiles - 1) / tiles;
+    int ms = (want + wgs - 1) / wgs;
     if (ms > steps / 4) ms = steps / 4;
     if (ms < 1) ms = 1;
     const int sper = (steps + ms - 1) / ms;
     ms = (steps + sper - 1) / sper;
     // too few workgroups, or so few output tiles that the launch is all partial-tile traffic (the 64 -> 128 channel layers:
     // 4 tiles x 64 slices, 38 us on wgrad.hip against 46 us here); knob 4 = 8: whenever the geometry fits
-    if (k4 != 8 && ((long long)tiles * ms < 96 || tiles < 8)) return false;
+    if (k4 != 8 && ((long long)wgs * ms < 96 || tiles < 8)) return false;
     if (slices) *slices = ms;
     if (tx_out) *tx_out = tx;
     if (steps_out) *steps_out = steps;
@@ -404,9 +474,21 @@ int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name) 
     k.tiles_x = (a->wq + tx - 1) / tx; k.tiles_y = (a->hq + ty - 1) / ty;
     k.nsteps = steps; k.msplit = ms; k.sper = (steps + ms - 1) / ms;
     k.itiles = k.dp / 128; k.ctiles = k.gp / 64;
-    k.nwg = k.itiles * 4 * k.ctiles * ms;
+    const int nky = pfa_wgrad_patch_nky(a->stride, tx);
+    k.nwg = k.itiles * (4 / nky) * k.ctiles * ms;
     k.stamps = (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)k.nwg * 64) ? (unsigned long long*)g_pfa_dbgbuf : nullptr;
     int rc;
+    if (a->stride == 2 && tx == 32 && nky == 2 && pfa_knob(7) >= 11 && pfa_knob(7) <= 17) {   // developer ablations (results are wrong)
+        switch (pfa_knob(7) - 10) {
+            case 1: rc = launch_wgp<2, 32, 1, 2>(k, st); break;
+            case 2: rc = launch_wgp<2, 32, 2, 2>(k, st); break;
+            case 3: rc = launch_wgp<2, 32, 3, 2>(k, st); break;
+            case 4: rc = launch_wgp<2, 32, 4, 2>(k, st); break;
+            case 5: rc = launch_wgp<2, 32, 5, 2>(k, st); break;
+            case 6: rc = launch_wgp<2, 32, 6, 2>(k, st); break;
+            default: rc = launch_wgp<2, 32, 7, 2>(k, st); break;
+        }
+    } else
     if (a->stride == 2 && tx == 32 && pfa_knob(7) >= 11 && pfa_knob(7) <= 17) {        // developer ablations (results are wrong)
         switch (pfa_knob(7) - 10) {
             case 1: rc = launch_wgp<2, 32, 1>(k, st); break;
@@ -417,6 +499,10 @@ int pfa_wgrad_patch(const pfa_wgrad_args* a, hipStream_t st, const char** name) 
             case 6: rc = launch_wgp<2, 32, 6>(k, st); break;
             default: rc = launch_wgp<2, 32, 7>(k, st); break;
         }
+    } else
+    if (nky == 2) {
+        if (a->stride == 1) rc = tx == 32 ? launch_wgp<1, 32, 0, 2>(k, st) : launch_wgp<1, 16, 0, 2>(k, st);
+        else rc = tx == 32 ? launch_wgp<2, 32, 0, 2>(k, st) : launch_wgp<2, 16, 0, 2>(k, st);
     } else
     if (a->stride == 1) rc = tx == 32 ? launch_wgp<1, 32>(k, st) : launch_wgp<1, 16>(k, st);
     else rc = tx == 32 ? launch_wgp<2, 32>(k, st) : launch_wgp<2, 16>(k, st);

@@ -72,7 +72,9 @@ uint64_t pfa_launch_count(void);
  * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong;
  * id 8: workgroups a weight-gradient patch launch wants (0 = 128); id 9: workgroup count from which transposed
  * convolutions take four-class workgroups, id 10: 128-channel tile count below which stride-1 convolutions slice K (0 = 192); id 11: Adam grid (0 = default);
- * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256). */
+ * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256);
+ * id 13: two tap rows per workgroup in the patch weight gradient (wgrad_patch.hip): 2 = always, 3 = where its ring keeps
+ * four stages (stride 1, 4x16 tile). */
 int pfa_set_knob(int id, int value);
 /* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write clock stamps per
  * workgroup: conv (uint64[workgroups][16]: 8 shader-clock stamps - entry, first fragments, K loop done, accumulators in LDS,

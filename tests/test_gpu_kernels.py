@@ -876,7 +876,7 @@ WGP_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, ou
 def test_wgrad_patch_kernel(case, ws):
     """Weight gradients on the patch kernel of wgrad_patch.hip (pfa_set_knob(4, 8) routes launches this small there): the
     oracle and the older kernel (knob 4 = 7) - both strides, both tile shapes, ragged maps, the decoder's virtual concat on
-    the direct side, float atomics and the slab + ordered reduce."""
+    the direct side, float atomics and the slab + ordered reduce; one and two tap rows per workgroup (knob 13)."""
     name, kind, n, cins, h, w, co, stride, slab = case
     dtype = torch.bfloat16
     ci = sum(cins)
@@ -897,9 +897,10 @@ def test_wgrad_patch_kernel(case, ws):
     dyt = to_nhwc(dy, dtype)
     lib = _lib.lib()
     res = []
-    for knob in (8, 7):
+    for knob, nky in ((8, 1), (7, 1), (8, 2)):                                           # (knob 13 = 2: two tap rows per workgroup)
         dw = torch.full((rows, 16, cols), 0.5, dtype=torch.float32, device="cuda")       # the result is ADDED to dw
         lib.pfa_set_knob(4, knob)
+        lib.pfa_set_knob(13, nky)
         lib.pfa_gather_timing(1)
         try:
             before = _lib.launch_count()
@@ -916,11 +917,13 @@ def test_wgrad_patch_kernel(case, ws):
         finally:
             lib.pfa_gather_timing(0)
             lib.pfa_set_knob(4, 0)
+            lib.pfa_set_knob(13, 0)
         assert nm.value.decode().startswith("k_wgrad_patch") == (knob == 8), nm.value
         assert launches == (2 if slab else 1)
         res.append((dw.cpu().numpy() - 0.5).reshape(rows, 4, 4, cols).transpose(0, 3, 1, 2))
     close(res[0], want, torch.float32, name)
     close(res[0], res[1], torch.float32, name + " vs wgrad.hip", scale=np.abs(want).max())
+    close(res[2], want, torch.float32, name + " two tap rows per workgroup")
 
 
 @pytest.mark.parametrize("case", [("conv_co320", "conv", 2, [32], 32, 32, 320, 2), ("convT_ci256_cat", "convT", 2, [128, 128], 16, 16, 24, 2),

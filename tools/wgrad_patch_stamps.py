@@ -11,6 +11,8 @@ L = [("c4", 1, (31, 31, [512]), (32, 32, 256)), ("e3/c3", 2, (32, 32, [256]), (6
 lib = _lib.lib()
 buf = torch.zeros(8192 * 8, dtype=torch.int64, device='cuda')
 import os
+nky = int(os.environ.get("WG_NKY", "1"))                 # 2: two tap rows per workgroup (knob 13)
+lib.pfa_set_knob(13, nky)
 knobs = [0] + ([11, 12, 14, 13, 15, 16, 17] if os.environ.get("PFA_ABLATE") else [])
 names = {0: "full", 11: "no MFMA", 12: "no reads", 14: "no DMA", 13: "no MFMA, no reads", 15: "no MFMA, no DMA", 16: "no reads, no DMA",
          17: "barriers + waits + addresses"}
@@ -36,7 +38,7 @@ for knob in knobs:
       ty = 2 if wq >= 24 else 4
       steps_total = B * ((hq + ty - 1) // ty) * ((wq + 64 // ty - 1) // (64 // ty))
       nwg = st.shape[0]
-      tiles = (sum(dparts) // 128) * 4 * (gc // 64)
+      tiles = (sum(dparts) // 128) * (4 // nky) * (gc // 64)
       ms = nwg // tiles
       sper = (steps_total + ms - 1) // ms
       life = float((st[:, 5] - st[:, 4]).median()) / 100.0
@@ -45,3 +47,4 @@ for knob in knobs:
             f"epilogue {epi:7.0f} | life {life:6.1f} us, first start -> last end {span:6.1f} us")
 
 lib.pfa_set_knob(7, 0)
+lib.pfa_set_knob(13, 0)
