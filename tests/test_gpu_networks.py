@@ -918,3 +918,37 @@ def test_launch_list_records_calls_events_and_replays():
     bad = _lib.LaunchList([_lib.ReplayOp(_lib.OP_CALL, 9999, 1, None)], [])
     with pytest.raises(_lib.PfaError, match="op 0"):
         bad.replay()
+
+
+def test_step_marks_follow_the_phases_of_the_step():
+    """GanTrainer.marks (tools/step_marks.py): timing events at the phase boundaries of the three-stream step - one set per
+    step, in program order on the main stream, D(real) complete before the discriminator's gradients are - and the marked
+    steps compute what unmarked steps do."""
+    def run(marked):
+        torch.manual_seed(3)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda()
+        tr = pfa_gan.GanTrainer(G, D, precision="bf16", inputs_resident=True)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        a = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+        b = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+        xa, xb = tr.pack(a), tr.pack(b)
+        torch.cuda.synchronize()
+        if marked:
+            tr.marks = []
+        out = [tr.step_packed(xa, xb).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        return tr, torch.stack(out), tr.opt_g.flat().data.clone()
+    tr, marked, pm = run(True)
+    _, plain, pp = run(False)
+    assert torch.equal(pm, pp)                                         # (trained state: bitwise; the loss sums: float atomics)
+    assert torch.allclose(marked, plain, rtol=1e-5, atol=1e-6)
+    names = [n for n, _ in tr.marks]
+    per = len(names) // 3
+    assert len(names) == 3 * per and names[:per] == names[per:2 * per] == names[2 * per:]
+    assert names[0] == "step" and names[per - 1].startswith("G gradients")
+    at = {n: e for n, e in tr.marks[per:2 * per]}                      # the second step
+    main = [n for n in names[:per] if not n.startswith("side:")]
+    t = [at["step"].elapsed_time(at[n]) for n in main]
+    assert all(t[i] <= t[i + 1] for i in range(len(t) - 1)), list(zip(main, t))
+    assert at["side: D(real) backward done"].elapsed_time(at["D gradients complete"]) >= 0
