@@ -307,7 +307,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_bce_logits(const T* __restrict__ logits, int64_t count, int ld, float target,
-                                                    float lscale, float gscale, float* loss_acc, T* dlogits) {
+                                                    float lscale, float gscale, float* loss_acc, T* dlogits, int parts) {
     constexpr int CH = ElemTraits<T>::CH;
     __shared__ float sh[4];
     float local = 0.f;
@@ -326,14 +326,18 @@ __global__ __launch_bounds__(256) void k_bce_logits(const T* __restrict__ logits
         }
     }
     const float t = block_sum(local, sh);
-    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, lscale * t / (float)count);
+    // parts: one partial per workgroup (added in index order by k_loss_finish: reproducible) instead of a float atomic
+    if (threadIdx.x == 0 && loss_acc) {
+        if (parts) loss_acc[blockIdx.x] = lscale * t / (float)count;
+        else atomicAdd(loss_acc, lscale * t / (float)count);
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_l1_tanh_bwd(const T* __restrict__ fake, const T* __restrict__ real,
                                                      int64_t count, int ld, int c_real, const T* __restrict__ dgan,
                                                      int dgan_ld, int dgan_off, float lambda, float* loss_acc,
-                                                     T* dpre) {
+                                                     T* dpre, int parts) {
     constexpr int CH = ElemTraits<T>::CH;
     __shared__ float sh[4];
     const int cpr = ld / CH;
@@ -362,7 +366,29 @@ __global__ __launch_bounds__(256) void k_l1_tanh_bwd(const T* __restrict__ fake,
         if (dpre) o.store(dpre + idx * CH);
     }
     const float t = block_sum(local, sh);
-    if (threadIdx.x == 0 && loss_acc) atomicAdd(loss_acc, lambda * t * inv);
+    if (threadIdx.x == 0 && loss_acc) {
+        if (parts) loss_acc[blockIdx.x] = lambda * t * inv;
+        else atomicAdd(loss_acc, lambda * t * inv);
+    }
+}
+
+// out[0] = sum parts[b0 .. e0) + sum parts[b1 .. e1), out[1] = sum parts[b2 .. e2) + sum parts[b3 .. e3) (b2 < 0: out[0] only):
+// one workgroup, every range in a fixed order (lane-strided, then the wave / block tree of block_sum)
+struct LossRanges { int b[4], e[4]; };
+__global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ parts, const LossRanges r, float* out) {
+    __shared__ float sh[4];
+    float res[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float local = 0.f;
+        for (int i = r.b[k] + (int)threadIdx.x; i < r.e[k]; i += 256) local += parts[i];
+        res[k] = block_sum(local, sh);
+        __syncthreads();                         // sh is reused by the next range
+    }
+    if (threadIdx.x == 0) {
+        out[0] = res[0] + res[1];
+        if (r.b[2] >= 0) out[1] = res[2] + res[3];
+    }
 }
 
 // ------------------------------------------------------------------ column sums
@@ -707,32 +733,73 @@ extern "C" int pfa_bn_bwd_apply(const void* dy, const void* raw, int64_t rows, i
     return 0;
 }
 
-extern "C" int pfa_bce_logits(const void* logits, int64_t count, int ld, int dtype, float target, float lscale,
-                              float gscale, float* loss_acc, void* dlogits, pfa_stream s) {
+static int bce_logits_launch(const void* logits, int64_t count, int ld, int dtype, float target, float lscale,
+                             float gscale, float* loss_acc, void* dlogits, pfa_stream s, int parts) {
     PFA_REQUIRE(logits && count > 0 && ld > 0 && ld % pfa_ch(dtype) == 0, "pfa_bce_logits: bad arguments");
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(k_bce_logits<bf16_t>, dim3(grid_for(count, 256, 64)), dim3(256), 0, (hipStream_t)s,
-                                  (const bf16_t*)logits, count, ld, target, lscale, gscale, loss_acc, (bf16_t*)dlogits),
+                                  (const bf16_t*)logits, count, ld, target, lscale, gscale, loss_acc, (bf16_t*)dlogits, parts),
                hipLaunchKernelGGL(k_bce_logits<float>, dim3(grid_for(count, 256, 64)), dim3(256), 0, (hipStream_t)s,
-                                  (const float*)logits, count, ld, target, lscale, gscale, loss_acc, (float*)dlogits));
+                                  (const float*)logits, count, ld, target, lscale, gscale, loss_acc, (float*)dlogits, parts));
     PFA_LAUNCHED("k_bce_logits");
     return 0;
 }
 
-extern "C" int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
-                               const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
-                               pfa_stream s) {
+extern "C" int pfa_bce_logits(const void* logits, int64_t count, int ld, int dtype, float target, float lscale,
+                              float gscale, float* loss_acc, void* dlogits, pfa_stream s) {
+    return bce_logits_launch(logits, count, ld, dtype, target, lscale, gscale, loss_acc, dlogits, s, 0);
+}
+
+extern "C" int pfa_bce_logits_parts(const void* logits, int64_t count, int ld, int dtype, float target, float lscale,
+                                    float gscale, float* parts, void* dlogits, pfa_stream s) {
+    PFA_REQUIRE(parts, "pfa_bce_logits_parts: no partials buffer");
+    return bce_logits_launch(logits, count, ld, dtype, target, lscale, gscale, parts, dlogits, s, 1);
+}
+
+extern "C" int pfa_bce_logits_nparts(int64_t count) { return count > 0 ? grid_for(count, 256, 64) : 0; }
+
+static int l1_tanh_bwd_launch(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                              const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
+                              pfa_stream s, int parts) {
     PFA_REQUIRE(fake && real && count > 0 && ld > 0 && ld % pfa_ch(dtype) == 0 && c_real > 0 && c_real <= ld,
                 "pfa_l1_tanh_bwd: bad arguments");
     const int64_t nchunks = count * (ld / pfa_ch(dtype));
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(k_l1_tanh_bwd<bf16_t>, dim3(grid_for(nchunks, 256, 1024)), dim3(256), 0,
                                   (hipStream_t)s, (const bf16_t*)fake, (const bf16_t*)real, count, ld, c_real,
-                                  (const bf16_t*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (bf16_t*)dpre),
+                                  (const bf16_t*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (bf16_t*)dpre, parts),
                hipLaunchKernelGGL(k_l1_tanh_bwd<float>, dim3(grid_for(nchunks, 256, 1024)), dim3(256), 0,
                                   (hipStream_t)s, (const float*)fake, (const float*)real, count, ld, c_real,
-                                  (const float*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (float*)dpre));
+                                  (const float*)dgan, dgan_ld, dgan_off, lambda, loss_acc, (float*)dpre, parts));
     PFA_LAUNCHED("k_l1_tanh_bwd");
+    return 0;
+}
+
+extern "C" int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                               const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
+                               pfa_stream s) {
+    return l1_tanh_bwd_launch(fake, real, count, ld, c_real, dtype, dgan, dgan_ld, dgan_off, lambda, loss_acc, dpre, s, 0);
+}
+
+extern "C" int pfa_l1_tanh_bwd_parts(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                                     const void* dgan, int dgan_ld, int dgan_off, float lambda, float* parts, void* dpre,
+                                     pfa_stream s) {
+    PFA_REQUIRE(parts, "pfa_l1_tanh_bwd_parts: no partials buffer");
+    return l1_tanh_bwd_launch(fake, real, count, ld, c_real, dtype, dgan, dgan_ld, dgan_off, lambda, parts, dpre, s, 1);
+}
+
+extern "C" int pfa_l1_tanh_bwd_nparts(int64_t count, int ld, int dtype) {
+    if (count <= 0 || ld <= 0 || pfa_ch(dtype) <= 0) return 0;
+    return grid_for(count * (ld / pfa_ch(dtype)), 256, 1024);
+}
+
+extern "C" int pfa_loss_finish(const float* parts, int b0, int e0, int b1, int e1, int b2, int e2, int b3, int e3, float* out,
+                               pfa_stream s) {
+    PFA_REQUIRE(parts && out && b0 >= 0 && b1 >= 0 && (b2 < 0 || b3 >= 0), "pfa_loss_finish: bad arguments");
+    LossRanges r;
+    r.b[0] = b0; r.e[0] = e0; r.b[1] = b1; r.e[1] = e1; r.b[2] = b2; r.e[2] = e2; r.b[3] = b3; r.e[3] = e3;
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, (hipStream_t)s, parts, r, out);
+    PFA_LAUNCHED("k_loss_finish");
     return 0;
 }
 

@@ -98,6 +98,12 @@ PROTOTYPES = {
     "pfa_bce_logits": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "pfa_l1_tanh_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
                                 c_void_p, c_void_p, c_void_p]),
+    "pfa_bce_logits_nparts": (c_int, [c_int64]),
+    "pfa_bce_logits_parts": (c_int, [c_void_p, c_int64, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "pfa_l1_tanh_bwd_nparts": (c_int, [c_int64, c_int, c_int]),
+    "pfa_l1_tanh_bwd_parts": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float,
+                                      c_void_p, c_void_p, c_void_p]),
+    "pfa_loss_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_colsum_ws": (c_size_t, [c_int64, c_int]),
     "pfa_colsum": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfa_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int,

@@ -457,6 +457,41 @@ def l1_tanh_bwd(fake, real, c_real, dgan, dgan_off, lam, loss_acc, dpre):
                                 ptr(loss_acc), ptr(dpre), stream()), "pfa_l1_tanh_bwd")
 
 
+# Reproducible loss sums: one partial per workgroup into `parts` (a float32 tensor of at least *_nparts elements), added in
+# index order by loss_finish - no float atomics, the same bits on every run.
+def bce_logits_nparts(logits):
+    return int(lib().pfa_bce_logits_nparts(rows_of(logits)))
+
+
+def bce_logits_parts(logits, target, lscale, gscale, parts, dlogits):
+    """-> number of partials written (parts[0 .. n))"""
+    n = bce_logits_nparts(logits)
+    if parts.numel() < n:
+        raise _lib.PfaError("bce_logits_parts: partials buffer too small")
+    check(lib().pfa_bce_logits_parts(ptr(logits), rows_of(logits), logits.shape[3], dt_code(logits.dtype), float(target),
+                                     float(lscale), float(gscale), ptr(parts), ptr(dlogits), stream()), "pfa_bce_logits_parts")
+    return n
+
+
+def l1_tanh_bwd_parts(fake, real, c_real, dgan, dgan_off, lam, parts, dpre):
+    n = int(lib().pfa_l1_tanh_bwd_nparts(rows_of(fake), fake.shape[3], dt_code(fake.dtype)))
+    if parts.numel() < n:
+        raise _lib.PfaError("l1_tanh_bwd_parts: partials buffer too small")
+    check(lib().pfa_l1_tanh_bwd_parts(ptr(fake), ptr(real), rows_of(fake), fake.shape[3], c_real, dt_code(fake.dtype),
+                                      ptr(dgan), dgan.shape[3] if dgan is not None else 0, dgan_off, float(lam),
+                                      ptr(parts), ptr(dpre), stream()), "pfa_l1_tanh_bwd_parts")
+    return n
+
+
+def loss_finish(parts, ranges, out):
+    """out[0] = sum of parts over ranges[0] and ranges[1]; with four ranges also out[1] = ... over ranges[2] and ranges[3].
+    A range is (begin, end)."""
+    if len(ranges) not in (2, 4) or any(e < b or b < 0 or e > parts.numel() for b, e in ranges):
+        raise _lib.PfaError("loss_finish: two or four (begin, end) ranges inside the partials buffer")
+    flat = [int(v) for r in ranges for v in r] + ([-1, -1, -1, -1] if len(ranges) == 2 else [])
+    check(lib().pfa_loss_finish(ptr(parts), *flat, ptr(out), stream()), "pfa_loss_finish")
+
+
 def colsum(x, out, ws, c_out=None):
     """out[j] += sum over pixels of x[..., j], j < c_out (default: len(out))."""
     rows, c = rows_of(x), x.shape[3]

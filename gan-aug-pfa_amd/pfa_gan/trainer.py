@@ -188,7 +188,10 @@ class GanTrainer:
         self._d_free_recorded = False
         self.inputs_resident = bool(inputs_resident)
         self.marks = None
-        self._loss_real = torch.zeros(1, dtype=torch.float32, device=dev)
+        # Loss sums without float atomics: the loss kernels store one partial per workgroup - D(real) | D(fake) | G's BCE (64
+        # each at most) | L1 (1024) - and one launch at the end of the step adds them in index order: the same bits every run.
+        self._parts = torch.zeros(3 * 64 + 1024, dtype=torch.float32, device=dev)
+        self._nparts = [0, 0, 0, 0]
         self._graphs = None
         self._listing = False          # launch lists are being warmed up / recorded / replayed (use_graph == "replay")
         self._ev_static = torch.cuda.Event() if overlap else None      # the static input copies of a replayed step are complete
@@ -207,19 +210,20 @@ class GanTrainer:
 
     def _d_phase(self, xa, xb, graph_safe, ready=None):
         G, Dn = self.G, self.Dn
-        K.fill_zero(self.losses)
+        parts = self._parts
         garena = self.opt_d.flat().grad
         if self.side is None:
             self.opt_d.zero_grad()
             fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-            K.bce_logits(lr, 1.0, 0.5, 0.5, self.losses[0:1], dl_r)
+            self._nparts[0] = K.bce_logits_parts(lr, 1.0, 0.5, 0.5, parts[0:64], dl_r)
             lf = Dn.forward([xa, fake], self.ctx_f, train=True)
             dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
-            K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
+            self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
             Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
             Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, fresh=False)      # accumulates into the first pass's arena
+            K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
             return
         # Three streams.  side: the whole D(real) forward + backward (it needs neither the generator nor D(fake)) into
         # the second gradient arena; main: G forward -> D(fake) forward -> D(fake) dgrad/BatchNorm chain; side2: D(fake)'s
@@ -230,8 +234,8 @@ class GanTrainer:
         # (free once the previous step's G-phase D backward is done: _ev_d_free) and the inputs - nothing of the
         # previous step's generator backward / Adam(G) / shadow refresh / gradient zero-fills.  With inputs_resident
         # the side stream therefore waits for _ev_d_free only, and this step's D(real) runs under the HBM-bound tail of
-        # the previous step instead of after it.  Its loss goes to a slot of its own (the main stream zeroes `losses`
-        # later than the side stream may already have added to it) and its gradient arena is zeroed on the side stream.
+        # the previous step instead of after it.  Its loss partials have a range of their own (read by this step's loss_finish
+        # below, i.e. before the _ev_d_free the NEXT step's D(real) waits for) and its gradient arena is zeroed on the side stream.
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
         # (a captured hipGraph cannot wait for an event of another graph; a launch list can: it re-issues the same waits)
@@ -246,10 +250,9 @@ class GanTrainer:
         with torch.cuda.stream(self.side):
             self._mark("side: D(real) begins")
             K.fill_zero(garena2)
-            K.fill_zero(self._loss_real)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-            K.bce_logits(lr, 1.0, 0.5, 0.5, self._loss_real, dl_r)
+            self._nparts[0] = K.bce_logits_parts(lr, 1.0, 0.5, 0.5, parts[0:64], dl_r)
             K.record_event(self._ev_real_fwd, self.side)
             self._mark("side: D(real) forward done")
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True, side=self.side2 if DREAL_WGRAD_SIDE else None)
@@ -259,7 +262,7 @@ class GanTrainer:
         K.wait_event(main, self._ev_real_fwd)
         lf = Dn.forward([xa, fake], self.ctx_f, train=True)
         dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
-        K.bce_logits(lf, 0.0, 0.5, 0.5, self.losses[0:1], dl_f)
+        self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
         self._mark("D(fake) forward done")
         # (side is free again: D(real) finished under the generator's forward)
         Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2)
@@ -267,7 +270,8 @@ class GanTrainer:
         K.wait_stream(main, self.side)
         K.wait_stream(main, self.side2)
         self._mark("D gradients complete")
-        K.axpy(self.losses[0:1], self._loss_real)
+        # loss_d of this step (before _ev_d_free: the next step's D(real) may overwrite its partials from there on)
+        K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
@@ -278,14 +282,14 @@ class GanTrainer:
         fake = self.gctx.v["fake"]
         lg = Dn.forward([xa, fake], self.ctx_r, train=True)
         dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
-        K.bce_logits(lg, 1.0, 1.0, 1.0, self.losses[1:2], dl_g)
+        self._nparts[2] = K.bce_logits_parts(lg, 1.0, 1.0, 1.0, self._parts[128:192], dl_g)
         dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
         if self._ev_d_free is not None and (not graph_safe or self._listing):
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
         self._mark("G phase: D forward + input gradient done")
         dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
-        K.l1_tanh_bwd(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self.losses[1:2], dpre)
+        self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self._parts[192:], dpre)
         garena = self.opt_g.flat().grad
         self._works = []
         hook = None
@@ -329,6 +333,8 @@ class GanTrainer:
                    side=(self.side, self.side3) if self.side is not None and self.side3 is not None else self.side,
                    bucket_ready=hook)
         self._mark("G backward chain done")
+        # loss_g of this step (here: the main stream would otherwise only wait for the side streams)
+        K.loss_finish(self._parts, [(128, 128 + self._nparts[2]), (192, 192 + self._nparts[3])], self.losses[1:2])
         if self.side is not None:
             K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:

@@ -280,6 +280,21 @@ int pfa_bce_logits(const void* logits, int64_t count, int ld, int dtype, float t
 int pfa_l1_tanh_bwd(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
                     const void* dgan, int dgan_ld, int dgan_off, float lambda, float* loss_acc, void* dpre,
                     pfa_stream s);
+/* The same two kernels with REPRODUCIBLE loss sums: every workgroup stores its partial - parts[0 .. n) with n =
+ * pfa_bce_logits_nparts(count) <= 64 / pfa_l1_tanh_bwd_nparts(count, ld, dtype) <= 1024 - instead of adding to an
+ * accumulator with float atomics (whose order varies run to run); pfa_loss_finish then adds ranges of partials in index
+ * order: out[0] = sum parts[b0, e0) + sum parts[b1, e1), out[1] = sum parts[b2, e2) + sum parts[b3, e3) (an empty range:
+ * b == e; b2 < 0: out[0] only).  The fused step (GanTrainer) uses these: its loss scalars are bitwise the same on every run. */
+int pfa_bce_logits_nparts(int64_t count);
+int pfa_bce_logits_parts(const void* logits, int64_t count, int ld, int dtype, float target, float lscale, float gscale,
+                         float* parts, void* dlogits, pfa_stream s);
+int pfa_l1_tanh_bwd_nparts(int64_t count, int ld, int dtype);
+int pfa_l1_tanh_bwd_parts(const void* fake, const void* real, int64_t count, int ld, int c_real, int dtype,
+                          const void* dgan, int dgan_ld, int dgan_off, float lambda, float* parts, void* dpre,
+                          pfa_stream s);
+int pfa_loss_finish(const float* parts, int b0, int e0, int b1, int e1, int b2, int e2, int b3, int e3, float* out,
+                    pfa_stream s);
+
 /* out[j] += sum_rows x[row][j] for j < c_out <= c (bias gradients; accumulates like every gradient output).
  * ws: >= pfa_colsum_ws(rows,c) floats. */
 size_t pfa_colsum_ws(int64_t rows, int c);

@@ -1201,6 +1201,53 @@ def test_losses(dtype, ws):
     close(cs.cpu().numpy()[:3], from_nhwc(dpre, 3).astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, "colsum")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+def test_losses_from_partials_are_reproducible(dtype):
+    """pfa_bce_logits_parts / pfa_l1_tanh_bwd_parts + pfa_loss_finish: one partial per workgroup added in index order - the
+    oracle's losses and gradients (train_gan.py:42-43,58-69), the accumulator form's values, and the same bits on every run
+    at a size with many workgroups."""
+    x = rnd(fill.uniform("glp.x", (16, 1, 30, 30), -4, 4), dtype)
+    xt = to_nhwc(x, dtype)
+    parts = torch.full((64 + 64 + 1024,), 3.0, device="cuda")               # (stale values: every used entry is overwritten)
+    dl = torch.full_like(xt, 7.0)
+    n1 = K.bce_logits_parts(xt, 1.0, 0.5, 0.5, parts[0:64], dl)
+    n0 = K.bce_logits_parts(xt, 0.0, 0.5, 0.5, parts[64:128], None)
+    assert n1 == n0 == K.bce_logits_nparts(xt) and 1 < n1 <= 64
+    f = rnd(np.tanh(fill.uniform("glp.f", (4, 3, 128, 128), -2, 2)), dtype)
+    r = rnd(fill.uniform("glp.r", (4, 3, 128, 128)), dtype)
+    cp = K.pad_ch(3, dtype)
+    ft, rt = to_nhwc(f, dtype), to_nhwc(r, dtype)
+    dpre = torch.full((4, 128, 128, cp), 7.0, dtype=dtype, device="cuda")
+    nl = K.l1_tanh_bwd_parts(ft, rt, 3, None, 0, 100.0, parts[128:], dpre)
+    assert 64 < nl <= 1024
+    out = torch.full((2,), -1.0, device="cuda")
+    K.loss_finish(parts, [(0, n1), (64, 64 + n0), (128, 128 + nl), (128, 128)], out)
+    l1, g1 = ops.bce_logits(x, 1.0)
+    l0, _ = ops.bce_logits(x, 0.0)
+    ll, gl = ops.l1_loss(f, r)
+    torch.cuda.synchronize()
+    close(out.cpu().numpy()[0], 0.5 * (l1 + l0), torch.float32, "bce loss from partials")
+    close(out.cpu().numpy()[1], 100.0 * ll, torch.float32, "l1 loss from partials")
+    close(from_nhwc(dl, 1), 0.5 * g1, dtype, "bce grad")
+    close(from_nhwc(dpre, 3), 100.0 * gl * (1 - f.astype(np.float64) ** 2), dtype, "dpre")
+    acc = torch.zeros(1, device="cuda")                                      # the accumulator form agrees to rounding
+    K.l1_tanh_bwd(ft, rt, 3, None, 0, 100.0, acc, None)
+    assert abs(float(acc[0]) - float(out[1])) <= 1e-5 * abs(float(out[1]))
+    one = torch.zeros(1, device="cuda")                                      # two ranges -> out[0] only
+    K.loss_finish(parts, [(128, 128 + nl), (0, 0)], one)
+    assert float(one[0]) == float(out[1])
+    for _ in range(5):                                                       # bitwise repeatable
+        p2 = torch.zeros_like(parts)
+        K.bce_logits_parts(xt, 1.0, 0.5, 0.5, p2[0:64], None)
+        K.bce_logits_parts(xt, 0.0, 0.5, 0.5, p2[64:128], None)
+        K.l1_tanh_bwd_parts(ft, rt, 3, None, 0, 100.0, p2[128:], None)
+        o2 = torch.zeros(2, device="cuda")
+        K.loss_finish(p2, [(0, n1), (64, 64 + n0), (128, 128 + nl), (128, 128)], o2)
+        assert torch.equal(o2, out)
+    with pytest.raises(_lib.PfaError):
+        K.loss_finish(parts, [(0, 4), (2, 1)], one)
+
+
 def test_adam():
     n = 1003
     p = fill.uniform("ga.p", (n,))
