@@ -32,6 +32,8 @@ __device__ __forceinline__ float row_sum16(float v) {      // sum over a DPP row
     return v;
 }
 
+constexpr int LOGIT_WROW = 8192 + 16;   // a workgroup's weight-gradient partials [16 taps][512] + the bias gradient's, padded
+
 struct LogitK {
     const char* x;           // [nb][h][w][c] bf16: the layer's input (forward, wgrad) / raw output of the layer below (dgrad)
     const bf16_t* wt;        // [16][c] bf16
@@ -42,6 +44,7 @@ struct LogitK {
     float* part;             // dgrad: [2][blocks][c] partial sums, or NULL
     float* dw;               // wgrad: [16][c] float32, +=
     float* db;
+    float* wslab;            // wgrad: [workgroups][LOGIT_WROW] partial rows, or NULL (float atomics)
     int nb, h, w, c, ld, act;
     float slope;
     int xtiles, rgroups;
@@ -294,8 +297,14 @@ __global__ __launch_bounds__(1024) void k_logit_wgrad(const LogitK p) {
         }
     }
     __syncthreads();
-    for (int q = tid; q < 8192; q += 1024) atomicAdd(p.dw + q, part[q] + part[8192 + q] + part[2 * 8192 + q] + part[3 * 8192 + q]);
-    if (p.db) {
+    // slab: this workgroup's sums as one row of partials (k_logit_wgrad_reduce adds the rows in order: reproducible);
+    // without a slab float atomics, whose order - and with it the last bits of dw - varies from run to run
+    float* row = p.wslab ? p.wslab + (size_t)blockIdx.x * LOGIT_WROW : nullptr;
+    for (int q = tid; q < 8192; q += 1024) {
+        const float v = part[q] + part[8192 + q] + part[2 * 8192 + q] + part[3 * 8192 + q];
+        if (row) row[q] = v; else atomicAdd(p.dw + q, v);
+    }
+    if (p.db || row) {
         __shared__ float bs[16];
         for (int off = 32; off > 0; off >>= 1) bsum += __shfl_xor(bsum, off);
         if ((tid & 63) == 0) bs[tid >> 6] = bsum;
@@ -303,9 +312,26 @@ __global__ __launch_bounds__(1024) void k_logit_wgrad(const LogitK p) {
         if (tid < 16) {
             float v = bs[tid];
             v = row_sum16(v);
-            if (tid == 15) atomicAdd(p.db, v);
+            if (tid == 15) { if (row) row[8192] = v; else atomicAdd(p.db, v); }
         }
     }
+}
+
+// dw[q] += sum over the workgroups' rows, in row order; element 8192 of a row is the bias gradient's partial
+__global__ __launch_bounds__(256) void k_logit_wgrad_reduce(const float* __restrict__ slab, int rows, float* dw, float* db) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q > 8192 || (q == 8192 && !db)) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= rows; r += 4) {
+        s0 += slab[(size_t)r * LOGIT_WROW + q];
+        s1 += slab[(size_t)(r + 1) * LOGIT_WROW + q];
+        s2 += slab[(size_t)(r + 2) * LOGIT_WROW + q];
+        s3 += slab[(size_t)(r + 3) * LOGIT_WROW + q];
+    }
+    for (; r < rows; ++r) s0 += slab[(size_t)r * LOGIT_WROW + q];
+    const float t = (s0 + s1) + (s2 + s3);
+    if (q == 8192) *db += t; else dw[q] += t;
 }
 
 }  // namespace
@@ -359,12 +385,14 @@ extern "C" int pfa_logit_dgrad(const void* dlogits, int ld, const void* w, const
     return 0;
 }
 
+extern "C" size_t pfa_logit_wgrad_slab_floats(int nb, int h) { return (size_t)nb * ((h + 3) / 4) * LOGIT_WROW; }
+
 extern "C" int pfa_logit_wgrad(const void* dlogits, int ld, const void* x, float* dw, float* db, int nb, int h, int wd, int c,
-                               pfa_stream s) {
+                               float* slab, pfa_stream s) {
     PFA_REQUIRE(dlogits && x && dw, "pfa_logit_wgrad: null pointer");
     LogitK k{};
     if (int rc = logit_common(k, nb, h, wd, c, ld)) return rc;
-    k.dl = (const char*)dlogits; k.x = (const char*)x; k.dw = dw; k.db = db;
+    k.dl = (const char*)dlogits; k.x = (const char*)x; k.dw = dw; k.db = db; k.wslab = slab;
     k.rgroups = (h + 3) / 4;
     const size_t lds = (size_t)7 * (wd + 4) * 4 + (size_t)4 * 16 * 512 * 4;
     PFA_REQUIRE(lds <= 159 * 1024, "pfa_logit_wgrad: image too wide");
@@ -376,5 +404,9 @@ extern "C" int pfa_logit_wgrad(const void* dlogits, int ld, const void* x, float
     }
     hipLaunchKernelGGL(k_logit_wgrad, dim3(nb * k.rgroups), dim3(1024), lds, (hipStream_t)s, k);
     PFA_LAUNCHED("k_logit_wgrad");
+    if (slab) {
+        hipLaunchKernelGGL(k_logit_wgrad_reduce, dim3(33), dim3(256), 0, (hipStream_t)s, (const float*)slab, nb * k.rgroups, dw, db);
+        PFA_LAUNCHED("k_logit_wgrad_reduce");
+    }
     return 0;
 }

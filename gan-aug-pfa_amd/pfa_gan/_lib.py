@@ -84,7 +84,8 @@ PROTOTYPES = {
     "pfa_logit_dgrad_tiles": (c_int, [c_int, c_int, c_int]),
     "pfa_logit_dgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "pfa_logit_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pfa_logit_wgrad_slab_floats": (c_size_t, [c_int, c_int]),
+    "pfa_logit_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p, c_float, c_float,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_eval_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

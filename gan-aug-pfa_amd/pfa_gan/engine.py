@@ -717,7 +717,7 @@ class DiscriminatorEngine(_Engine):
             if param_grads:
                 def pg(ws, L=L, dr=dr, inputs=inputs, logit=logit):
                     if logit:
-                        K.logit_wgrad(dr, inputs[0], L.dw(garena), L.db(garena) if L.b is not None else None)
+                        K.logit_wgrad(dr, inputs[0], L.dw(garena), L.db(garena) if L.b is not None else None, ws=ws)
                         return
                     K.wgrad([dr], inputs, L.dw(garena), L.stride, [L.cout], L.in_real, ws=ws, fresh=fresh)
                     if L.b is not None:

@@ -390,9 +390,11 @@ def logit_dgrad(dlogits, w, raw, scale, shift, mean, invstd, act, dy, ws):
     return part, nt
 
 
-def logit_wgrad(dlogits, x, dw, db):
+def logit_wgrad(dlogits, x, dw, db, ws=None):
+    """ws: Workspace for the partial rows of the reproducible form (ordered reduce); None: float atomics."""
     B, h, wd, c = x.shape
-    check(lib().pfa_logit_wgrad(ptr(dlogits), dlogits.shape[3], ptr(x), ptr(dw), ptr(db), B, h, wd, c, stream()),
+    slab = ws.get("logit_wgrad", lib().pfa_logit_wgrad_slab_floats(B, h)) if ws is not None else None
+    check(lib().pfa_logit_wgrad(ptr(dlogits), dlogits.shape[3], ptr(x), ptr(dw), ptr(db), B, h, wd, c, ptr(slab), stream()),
           "pfa_logit_wgrad")
 
 

@@ -213,7 +213,8 @@ class GanTrainer:
         parts = self._parts
         garena = self.opt_d.flat().grad
         if self.side is None:
-            self.opt_d.zero_grad()
+            garena2 = self.opt_d.grad2()      # an arena per pass, as on three streams: a second pass ADDING to the first
+            self.opt_d.zero_grad()            # one's sums would depend on the order of its float atomics
             fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
             lr = Dn.forward([xa, xb], self.ctx_r, train=True)
             dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
@@ -221,8 +222,8 @@ class GanTrainer:
             lf = Dn.forward([xa, fake], self.ctx_f, train=True)
             dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
             self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
-            Dn.backward(self.ctx_r, dl_r, garena, param_grads=True)
-            Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, fresh=False)      # accumulates into the first pass's arena
+            Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True)
+            Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
             K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
             return
         # Three streams.  side: the whole D(real) forward + backward (it needs neither the generator nor D(fake)) into
@@ -275,7 +276,7 @@ class GanTrainer:
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
-        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=self.side is not None)
+        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=True)
         Dn.refresh_shadows(force=True)
         self._mark("Adam(D) done")
         self.opt_g.zero_grad()
@@ -381,7 +382,7 @@ class GanTrainer:
             if opt is self.opt_g and getattr(self, "_g_reduced", False):
                 self._g_reduced = False          # already reduced bucket by bucket during the backward
                 return
-            if opt is self.opt_d and self.side is not None:      # fold the second arena in before the collective
+            if opt is self.opt_d:                                # fold the second arena in before the collective
                 opt.flat().grad.add_(opt.grad2())
                 opt.grad2().zero_()
             self._reduce(opt.flat().grad, "g" if opt is self.opt_g else "d")

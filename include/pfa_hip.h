@@ -206,9 +206,12 @@ int pfa_logit_dgrad_tiles(int nb, int h, int wd);
 int pfa_logit_dgrad(const void* dlogits, int ld, const void* w, const void* raw, const float* scale, const float* shift,
                     const float* mean, const float* invstd, int act, float slope, void* dy, float* part, int nb, int h,
                     int wd, int c, pfa_stream s);
-/* dw[tap][c] += sum_pixels dlogits * x[pixel + tap][c] (float atomics), db[0] += sum dlogits (db may be NULL). */
+/* dw[tap][c] += sum_pixels dlogits * x[pixel + tap][c], db[0] += sum dlogits (db may be NULL).  slab: caller-owned scratch
+ * of pfa_logit_wgrad_slab_floats(nb, h) floats - the workgroups' partial sums go there and a second launch adds them in a
+ * fixed order (bitwise reproducible); NULL: float atomics into dw / db, whose last bits vary from run to run. */
+size_t pfa_logit_wgrad_slab_floats(int nb, int h);
 int pfa_logit_wgrad(const void* dlogits, int ld, const void* x, float* dw, float* db, int nb, int h, int wd, int c,
-                    pfa_stream s);
+                    float* slab, pfa_stream s);
 
 /* ------------------------------------------------------------------ transposed conv onto <= 8 channels
  * out[b][2*iy-1+ky][2*ix-1+kx][co] = act( bias[co] + sum_c src[b][iy][ix][c] * w[co][ky*4+kx][c] )

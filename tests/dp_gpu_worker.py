@@ -75,9 +75,10 @@ def main():
         packed = [(t.pack(a), t.pack(b)) for t, (a, b) in zip(refs, [data(step, r) for r in range(world)])]
         for t, (xa, xb) in zip(refs, packed):
             t._d_phase(xa, xb, False)
-        gd = sum(t.opt_d.flat().grad for t in refs) / world
+        gd = sum(t.opt_d.flat().grad + t.opt_d.grad2() for t in refs) / world       # (an arena per D pass: real | fake)
         for t in refs:
             t.opt_d.flat().grad.copy_(gd)
+            t.opt_d.grad2().zero_()
         for t, (xa, xb) in zip(refs, packed):
             t._d_update_g_phase(xa, xb, False)
         gg = sum(t.opt_g.flat().grad for t in refs) / world

@@ -609,6 +609,21 @@ def test_logit_layer_kernels(case, ws):
     got_w = (gw - 0.5).cpu().numpy().reshape(1, 4, 4, c).transpose(0, 3, 1, 2)
     close(got_w, dw, torch.float32, name + ".dw", scale=np.abs(dw).max())
     close((gb - 0.25).cpu().numpy(), db, torch.float32, name + ".db", scale=max(np.abs(dl).sum(), 1.0))
+    # with a workspace: partial rows + ordered reduce - the same values, and the same bits on every run
+    runs = []
+    for _ in range(4):
+        gw2 = torch.full((1, 16, c), 0.5, dtype=torch.float32, device="cuda")
+        gb2 = torch.full((1,), 0.25, dtype=torch.float32, device="cuda")
+        before = _lib.launch_count()
+        K.logit_wgrad(dld, xd, gw2, gb2, ws=ws)
+        assert _lib.launch_count() - before == 2
+        runs.append((gw2.clone(), gb2.clone()))
+    torch.cuda.synchronize()
+    close((runs[0][0] - 0.5).cpu().numpy().reshape(1, 4, 4, c).transpose(0, 3, 1, 2), dw, torch.float32, name + ".dw (slab)",
+          scale=np.abs(dw).max())
+    close((runs[0][1] - 0.25).cpu().numpy(), db, torch.float32, name + ".db (slab)", scale=max(np.abs(dl).sum(), 1.0))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:]), name + ": not reproducible"
+    K.logit_wgrad(dld, xd, gw, None, ws=ws)                                     # (no bias gradient wanted)
 
 
 def test_logit_layer_support():

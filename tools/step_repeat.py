@@ -28,6 +28,17 @@ for it in range(reps):
         if hasattr(av, '_t') and hasattr(av, 'v'):
             for bn_, bt in av._t.items():
                 snap[an + ':' + bn_] = bt.detach().float().clone()
+    for on, opt in (("opt_g", tr.opt_g), ("opt_d", tr.opt_d)):             # parameters, gradient arenas, Adam moments
+        fl = opt.flat()
+        snap[on + ":params"] = fl.data.detach().clone()
+        snap[on + ":grads"] = fl.grad.detach().clone()
+        snap[on + ":m"] = opt.m.detach().clone()
+        snap[on + ":v"] = opt.v.detach().clone()
+        if getattr(opt, "_grad2", None) is not None:
+            snap[on + ":grads2"] = opt._grad2.detach().clone()
+    for mn, mod in (("G", G), ("D", D)):                                     # BatchNorm running buffers
+        for bn_, bt in mod.named_buffers():
+            snap[mn + ":" + bn_] = bt.detach().float().clone()
     snaps.append(snap)
 l0, f0, w0 = res[0]
 for it, (l, f, w) in enumerate(res):
