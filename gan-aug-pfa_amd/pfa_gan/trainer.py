@@ -102,11 +102,18 @@ class FusedAdam(torch.optim.Optimizer):
                    grad_scale=grad_scale, g2=g2)
 
     @torch.no_grad()
-    def step_begin(self):
-        """First half of a step taken range by range (step_range): one step count for all ranges."""
+    def step_begin(self, graph_safe=False):
+        """First half of a step taken range by range (step_range): one step count for all ranges.  graph_safe: the count is
+        read from device memory (ticked here once), so that a recorded launch list stays valid when it is replayed."""
         self.flat()
+        if graph_safe:
+            self.sync_step_dev()
         self.steps += 1
         self._flat.epoch += 1
+        self._range_dev = bool(graph_safe)
+        if graph_safe:
+            K.adam_tick(self.step_dev)
+            self._dev_steps += 1
 
     @torch.no_grad()
     def step_range(self, lo, hi, grad_scale=1.0):
@@ -114,6 +121,10 @@ class FusedAdam(torch.optim.Optimizer):
         last step_begin().  The fused trainer updates a bucket as soon as its gradients are final."""
         flat = self.flat()
         g = self.param_groups[0]
+        if getattr(self, "_range_dev", False):
+            K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
+                   g["eps"], 0, step_dev=self.step_dev, grad_scale=grad_scale)
+            return
         K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
                g["eps"], self.steps, grad_scale=grad_scale)
 
@@ -296,14 +307,17 @@ class GanTrainer:
         hook = None
         main = torch.cuda.current_stream()
         buckets = G.grad_buckets()[0]
-        bucketed = BUCKET_UPDATE and self.side is not None and self.side2 is not None and not graph_safe
+        # (a launch list re-issues library calls and events - the bucket hooks are just that; a captured hipGraph is kept to
+        # the whole-arena update, and so is a list when the buckets' all-reduces - torch calls - would have to be in it)
+        bucketed = BUCKET_UPDATE and self.side is not None and self.side2 is not None and (
+            not graph_safe or (self._listing and self.pg is None))
         if bucketed:
             # Update bucket by bucket while the backward is still running: a bucket of the gradient arena is final once
             # the side stream (weight gradients) and the main stream (BatchNorm gamma/beta gradients) reach the hook.
             # The second side stream - idle during the generator backward - then takes the bucket: [all-reduce over the
             # ranks ->] Adam on that range -> re-emit the kernel-side copies of its layers.  The decoder's bucket (63 % of
             # the parameters) is updated under the encoder backward; only the last, small bucket is left for the tail.
-            self.opt_g.step_begin()
+            self.opt_g.step_begin(graph_safe)
             scale = 1.0 / self.world
 
             def hook(i):
