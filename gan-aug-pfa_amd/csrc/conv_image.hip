@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct ImageK {
     GatherK g;
     int tiles_y, tiles_x, ntiles, nwg;      // ntiles: 64-channel tiles of the output (n = 64 or 128)
+    unsigned long long* stamps;             // developer timing (pfa_set_debug_buffer): 16 slots per workgroup, or NULL
 };
 
 constexpr int ITY = 8, ITX = 32;
@@ -43,6 +44,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
     const int qy0 = ty * ITY, qx0 = tx * ITX, n0 = nt * 64;
     const char* zero = (const char*)g_pfa_zero_page;
+    unsigned long long* stamps = q.stamps ? q.stamps + (size_t)blockIdx.x * 16 : nullptr;
+    auto stamp = [&](int k) { if (stamps && tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    if (stamps && tid == 0) stamps[8] = __builtin_amdgcn_s_memrealtime();
 
     // ---- one round of DMA: the patch of every source (pieces dealt round-robin over the waves), then the weights.
     // Patch slot s = (row r, plane pl, index i): input pixel (2 qy0 - 1 + r, 2 (qx0 + i) - 1 + pl).
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(1);
 
     // ---- MFMA 32x32x16: wave = 32 positions (tile row wave, all 32 columns) x 64 channels (two 32-row weight tiles).
     // k-step s, lane half lh: NSRC 1: tap 2 s + lh, the pixel's 8 channels; NSRC 2: tap s, source lh.
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     // ---- epilogue: accumulators -> fp32 [position][channel] image -> whole rows out
     constexpr int RS = patch_image_stride<64>();
     __syncthreads();                             // every wave is done with the patch and the weights
+    stamp(2);
     {
         char* row = smem + (wave * ITX + lr) * RS;
 #pragma unroll
@@ -112,13 +119,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
             }
     }
     __syncthreads();
+    stamp(3);
     auto pix_of = [&](int r, bool& valid, size_t& opix) {
         const int qy = qy0 + r / ITX, qx = qx0 + r % ITX;
         valid = qy < p.hq && qx < p.wq;
         opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
     };
     const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
-    patch_epilogue_rows<64>(p, n0, tid, 0, trow, smem, pix_of);
+    patch_epilogue_rows<64>(p, n0, tid, 0, trow, smem, pix_of, stamps);
+    if (stamps) {
+        stamp(6);
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp(7);
+        if (tid == 0) stamps[9] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <int NSRC>
@@ -160,6 +174,7 @@ int pfa_conv_image(const GatherK& k, hipStream_t st, const char** kernel_name) {
     q.tiles_y = (k.hq + ITY - 1) / ITY; q.tiles_x = (k.wq + ITX - 1) / ITX;
     q.ntiles = k.n / 64;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles;
+    q.stamps = (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 128) ? (unsigned long long*)g_pfa_dbgbuf : nullptr;
     if (kernel_name) *kernel_name = k.c2 ? "k_conv_image<2x8ch,64>" : "k_conv_image<8ch,64>";
     return k.c2 ? launch_image<2>(q, st) : launch_image<1>(q, st);
 }

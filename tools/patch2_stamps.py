@@ -20,6 +20,8 @@ L = [
  ("d4 fwd",    K.TCONV_S2, (16, 16, [512, 512]), 256, (16, 16)),
  ("e2/c2 dgrad", K.TCONV_S2, (64, 64, [128]), 64, (64, 64)),
  ("e3/c3 dgrad", K.TCONV_S2, (32, 32, [256]), 128, (32, 32)),
+ ("e1 fwd (image)", K.CONV_S2, (256, 256, [8]), 64, (128, 128)),
+ ("c1 fwd (image)", K.CONV_S2, (256, 256, [8, 8]), 64, (128, 128)),
 ]
 lib = _lib.lib()
 buf = torch.zeros(8192 * 16, dtype=torch.int64, device='cuda')
