@@ -1,19 +1,20 @@
 """Repeat one fused step from the same state many times and report run-to-run deviations (developer tool): a stale or
 racy hand-off shows as an outlier.  PFA_KNOBS selects the code path."""
 import sys
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd'); sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import numpy as np, torch
 import pfa_gan
-from oracle import fill, nets
 n, h, reps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
 overlap = (sys.argv[5] != "0") if len(sys.argv) > 5 else True
-gst = fill.fill_state(nets.g_state_shapes(), seed=21, bn_noise=False)
-dst = fill.fill_state(nets.d_state_shapes(), seed=22, bn_noise=False)
-a = torch.from_numpy(fill.uniform(f"fs.a.{n}.{h}", (n, 3, h, h))).cuda()
-b = torch.from_numpy(fill.uniform(f"fs.b.{n}.{h}", (n, 3, h, h))).cuda()
-def load(m, st): m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in st.items()}, strict=True)
+torch.manual_seed(21)                                    # one seeded start state (the modules' default init) and one batch
 G = pfa_gan.UNetGenerator(3, 3).cuda(); D = pfa_gan.NLayerDiscriminator(6).cuda()
+gst = {k: v.detach().clone() for k, v in G.state_dict().items()}
+dst = {k: v.detach().clone() for k, v in D.state_dict().items()}
+gen = torch.Generator(device="cuda").manual_seed(22)
+a = torch.rand((n, 3, h, h), device="cuda", generator=gen) * 2 - 1
+b = torch.rand((n, 3, h, h), device="cuda", generator=gen) * 2 - 1
+def load(m, st): m.load_state_dict({k: v.clone() for k, v in st.items()}, strict=True)
 res = []
 snaps = []
 for it in range(reps):
