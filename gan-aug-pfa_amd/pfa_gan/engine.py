@@ -497,12 +497,18 @@ class GeneratorEngine(_Engine):
     def grad_buckets(self):
         """Contiguous ranges of the gradient arena in the order the backward completes them:
         [decoder d7..d1] (final when the decoder loop ends), [e_{D-2}..e_D] (final after the three innermost
-        encoder levels), [e1..e_{D-3}] (end of backward).  Arena order is module.parameters() order:
-        e1, e2, bn2, ..., eD, dD, bnD, ..., d2, bn2, d1 - so each bucket is one slice."""
+        encoder levels), [e3..e_{D-3}] (after level e3), [e1, e2] (end of backward: a small last bucket keeps the update
+        that nothing can hide short).  Arena order is module.parameters() order: e1, e2, bn2, ..., eD, dD, bnD, ..., d2,
+        bn2, d1 - so each bucket is one slice.  -> (buckets, encoder levels (0-based) after which buckets 1.. are final; the
+        last bucket is final at the end)."""
         off = lambda L: self.flat.slots[id(L.w)][0]
         x_dec = off(self.up[self.D - 1])
-        x_mid = off(self.down[max(self.D - 3, 1)])
-        return [(x_dec, self.flat.total), (x_mid, x_dec), (0, x_mid)], max(self.D - 3, 1)
+        mid = max(self.D - 3, 1)
+        x_mid = off(self.down[mid])
+        if mid > 2:
+            x_low = off(self.down[2])
+            return [(x_dec, self.flat.total), (x_mid, x_dec), (x_low, x_mid), (0, x_low)], [mid, 2]
+        return [(x_dec, self.flat.total), (x_mid, x_dec), (0, x_mid)], [mid]
 
     def backward(self, ctx, dpre, garena, side=None, bucket_ready=None):
         """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena.
@@ -558,7 +564,7 @@ class GeneratorEngine(_Engine):
             else:
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
                 K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], g_up[k + 1]], (B, h, w), self.ws)
-        mid_level = self.grad_buckets()[1]
+        levels = self.grad_buckets()[1]
         self._join_sides(side)
         if bucket_ready is not None:
             bucket_ready(0)
@@ -596,12 +602,12 @@ class GeneratorEngine(_Engine):
                     g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                     K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
             # (after this level's input gradient, the last reader of its weights: the caller may update the bucket now)
-            if bucket_ready is not None and k == mid_level and k > 0:
+            if bucket_ready is not None and k in levels and k > 0:
                 self._join_sides(side)
-                bucket_ready(1)
+                bucket_ready(1 + levels.index(k))
         self._join_sides(side)
         if bucket_ready is not None:
-            bucket_ready(2 if mid_level > 0 else 1)
+            bucket_ready(len(levels) + 1)
 
 
 # ------------------------------------------------------------------------------------ discriminator

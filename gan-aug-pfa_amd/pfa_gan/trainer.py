@@ -348,6 +348,10 @@ class GanTrainer:
                    side=(self.side, self.side3) if self.side is not None and self.side3 is not None else self.side,
                    bucket_ready=hook)
         self._mark("G backward chain done")
+        if self.side is not None:
+            self._mark("side: G weight gradients done", self.side)
+        if bucketed:
+            self._mark("side2: bucket updates done", self.side2)
         # loss_g of this step (here: the main stream would otherwise only wait for the side streams)
         K.loss_finish(self._parts, [(128, 128 + self._nparts[2]), (192, 192 + self._nparts[3])], self.losses[1:2])
         if self.side is not None:
