@@ -685,25 +685,35 @@ class DiscriminatorEngine(_Engine):
         return (i == len(self.layers) - 1 and i > 0 and L.cout == 1 and L.stride == 1 and len(inputs) == 1
                 and K.logit_ok(inputs[0], L.cout_p))
 
+    def grad_bucket(self):
+        """-> (lo, level): [lo, total) of the gradient arena - the two innermost convolutions (76 % of the parameters) and the
+        BatchNorm between them - is final once the parameter gradients of layer `level` have been issued (arena order =
+        module.parameters() order: c1, c2, bn2, c3, bn3, c4, bn4, c5)."""
+        n = len(self.layers)
+        L = self.layers[n - 2]
+        return self.flat.slots[id(L.w)][0], n - 2
+
     def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None,
-                 fresh=True):
+                 fresh=True, bucket_ready=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55).
         need_dx: return dL/d(input) [B,H,W,sum(in_pad)]; with dx_part=i only the gradient of input source i
         ([B,H,W,in_pad[i]]) is computed - the G phase needs dL/dfake, not dL/dreal_A.
         fresh: garena holds zeros where this pass writes weight gradients (False for a second pass that accumulates into the
-        arena of a first one)."""
+        arena of a first one).
+        bucket_ready(): called when every kernel that writes grad_bucket()'s range has been issued (the caller may all-reduce
+        that range under the rest of the backward)."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
         K.set_phase(True)
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:
-            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh)
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh, bucket_ready)
         finally:
             self.ws_cur = self.ws
 
-    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True):
+    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True, bucket_ready=None):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -735,6 +745,9 @@ class DiscriminatorEngine(_Engine):
                     if L.b is not None:
                         K.colsum(dr, L.db(garena), ws, c_out=L.cout)
                 self._param_grads(None if i < D_WGRAD_MAIN_LEVELS else side, pg)
+                if bucket_ready is not None and i == n - 2:
+                    # (this layer's BatchNorm gradients were written with the fused finish of the layer above, on this stream)
+                    bucket_ready()
             if logit:
                 # input gradient fused with the LeakyReLU / BatchNorm backward of the layer below
                 Lp, prev = self.layers[i - 1], v["a"][i - 1]

@@ -26,6 +26,7 @@ import os as _os
 WGRAD_STREAMS = int(_os.environ.get("PFA_WGRAD_STREAMS", "1"))
 D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s weight gradients alternate between side2 and side
 DREAL_WGRAD_SIDE = _os.environ.get("PFA_DREAL_WGRAD_SIDE", "0") != "0"   # D(real)'s weight gradients on side2 instead of in line
+D_EARLY_REDUCE = _os.environ.get("PFA_D_EARLY_REDUCE", "1") != "0"     # data parallel: D's gradients reduced as they become final
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
 
 
@@ -250,6 +251,10 @@ class GanTrainer:
         # below, i.e. before the _ev_d_free the NEXT step's D(real) waits for) and its gradient arena is zeroed on the side stream.
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
+        # data parallel: the discriminator's gradients cross the ranks in three collectives instead of one behind the D phase
+        early_reduce = self.pg is not None and not graph_safe and D_EARLY_REDUCE
+        self._d_works = []
+        self._d_reduced = False
         # (a captured hipGraph cannot wait for an event of another graph; a launch list can: it re-issues the same waits)
         if (self.inputs_resident or ready is not None) and self._d_free_recorded and (not graph_safe or self._listing):
             K.wait_event(self.side, self._ev_d_free)
@@ -269,6 +274,10 @@ class GanTrainer:
             self._mark("side: D(real) forward done")
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True, side=self.side2 if DREAL_WGRAD_SIDE else None)
             self._mark("side: D(real) backward done")
+            if early_reduce and not DREAL_WGRAD_SIDE:
+                # D(real)'s arena is final here, long before the discriminator's update: its collective runs on the
+                # communicator's stream under the rest of the D phase
+                self._d_works.append(self._reduce(garena2, ("d", 2), async_op=True))
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
         self._mark("G forward done")
         K.wait_event(main, self._ev_real_fwd)
@@ -277,11 +286,25 @@ class GanTrainer:
         self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
         self._mark("D(fake) forward done")
         # (side is free again: D(real) finished under the generator's forward)
-        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2)
+        d_lo = Dn.grad_bucket()[0]
+
+        def d_bucket():
+            # c4 / c5 and the BatchNorm between them - 76 % of D(fake)'s gradients - are final: their weight gradients on
+            # side2, the BatchNorm gradients on the main stream.  The collective is enqueued behind side2 and runs on the
+            # communicator's stream under the rest of the backward.
+            K.wait_stream(self.side2, main)
+            with torch.cuda.stream(self.side2):
+                self._d_works.append(self._reduce(garena[d_lo:], ("d", 0), async_op=True))
+        bucketed_d = early_reduce and not D_WGRAD_PAIR and not DREAL_WGRAD_SIDE
+        Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2,
+                    bucket_ready=d_bucket if bucketed_d else None)
         self._mark("D(fake) backward chain done")
         K.wait_stream(main, self.side)
         K.wait_stream(main, self.side2)
         self._mark("D gradients complete")
+        if bucketed_d:                       # what is left: c1 .. c3 (and D(real)'s arena, reduced above)
+            self._d_works.append(self._reduce(garena[:d_lo], ("d", 1), async_op=True))
+            self._d_reduced = True
         # loss_d of this step (before _ev_d_free: the next step's D(real) may overwrite its partials from there on)
         K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
 
@@ -399,6 +422,12 @@ class GanTrainer:
         if self.pg is not None:
             if opt is self.opt_g and getattr(self, "_g_reduced", False):
                 self._g_reduced = False          # already reduced bucket by bucket during the backward
+                return
+            if opt is self.opt_d and getattr(self, "_d_reduced", False):
+                for w in self._d_works:          # the current stream waits for the collectives; no host sync
+                    w.wait()
+                self._d_works = []
+                self._d_reduced = False
                 return
             if opt is self.opt_d:                                # fold the second arena in before the collective
                 opt.flat().grad.add_(opt.grad2())
