@@ -252,7 +252,7 @@ class GanTrainer:
         main = torch.cuda.current_stream()
         garena2 = self.opt_d.grad2()
         # data parallel: the discriminator's gradients cross the ranks in three collectives instead of one behind the D phase
-        early_reduce = self.pg is not None and not graph_safe and D_EARLY_REDUCE
+        early_reduce = self.pg is not None and not graph_safe and D_EARLY_REDUCE and not D_WGRAD_PAIR and not DREAL_WGRAD_SIDE
         self._d_works = []
         self._d_reduced = False
         # (a captured hipGraph cannot wait for an event of another graph; a launch list can: it re-issues the same waits)
@@ -274,7 +274,7 @@ class GanTrainer:
             self._mark("side: D(real) forward done")
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True, side=self.side2 if DREAL_WGRAD_SIDE else None)
             self._mark("side: D(real) backward done")
-            if early_reduce and not DREAL_WGRAD_SIDE:
+            if early_reduce:
                 # D(real)'s arena is final here, long before the discriminator's update: its collective runs on the
                 # communicator's stream under the rest of the D phase
                 self._d_works.append(self._reduce(garena2, ("d", 2), async_op=True))
@@ -295,7 +295,7 @@ class GanTrainer:
             K.wait_stream(self.side2, main)
             with torch.cuda.stream(self.side2):
                 self._d_works.append(self._reduce(garena[d_lo:], ("d", 0), async_op=True))
-        bucketed_d = early_reduce and not D_WGRAD_PAIR and not DREAL_WGRAD_SIDE
+        bucketed_d = early_reduce
         Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2,
                     bucket_ready=d_bucket if bucketed_d else None)
         self._mark("D(fake) backward chain done")
