@@ -36,6 +36,9 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_PAIR = {256: 86.79e9, 512: 351.38e9}      # minimal schedule, conv MACs x2
 FLOP_PER_TILE = {256: 12.046e9, 512: 48.18e9}      # generator-only forward
+# SURVEY.md 8(d) "algorithmic bytes per img-pair" (ideal fusion: every conv pass touches input, output and weights once, bf16
+# activations, fp32 weight gradients, Adam 28 B/parameter), at the batch per GPU it is quoted for
+BYTES_PER_PAIR = {(256, 16): 237.5e6, (512, 8): 747.3e6}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
 
 
@@ -63,6 +66,8 @@ def parse():
                     help="D(real) of a step waits for the whole previous step (A/B switch for inputs_resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra legs of the training line: fp32 parity mode and generator-only inference (config 5)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of cpu_baseline_isolated
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
@@ -289,6 +294,83 @@ def cpu_baseline_isolated(size, budget_s, infer=False):
                     sample=f"cpu_baseline child exceeded {3 * budget_s + 60:.0f} s")
 
 
+# ----------------------------------------------------------------------------------------------------- extra legs
+def fp32_leg(args, pool32_src, steps=5, warmup=2):
+    """The parity mode (exact-f32 MFMA: the mode that meets the north star's 1e-3 / 1e-2 gate, and the reference's own
+    arithmetic, train_gan.py:46-75) on the SAME workload, a short pass after the headline measurement: fresh default networks,
+    the same synthetic batches, eager on three streams.  -> dict for the line's "fp32" key."""
+    import torch
+    import pfa_gan
+    torch.manual_seed(0)
+    gen = pfa_gan.UNetGenerator(3, 3).cuda()
+    disc = pfa_gan.NLayerDiscriminator(6).cuda()
+    tr = pfa_gan.GanTrainer(gen, disc, precision="fp32", overlap=not args.no_overlap, inputs_resident=True)
+    pool = [(tr.pack(a), tr.pack(b)) for a, b in pool32_src]
+    torch.cuda.synchronize()
+    for i in range(warmup):
+        tr.step_packed(*pool[i % len(pool)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step_packed(*pool[i % len(pool)])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = tr.losses.tolist()
+    assert all(l == l and abs(l) < 1e6 for l in losses), f"fp32 leg: non-finite loss {losses}"
+    value = args.batch * steps / dt
+    flop_pair = FLOP_PER_PAIR.get(args.size, 0)
+    return dict(value=round(value, 2), unit="img-pairs/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps, warmup=warmup,
+                dtype="fp32", algorithmic_tflops=round(value * flop_pair / 1e12, 2), peak=PEAK_F32_TFLOPS,
+                frac_of_peak=round(value * flop_pair / 1e12 / PEAK_F32_TFLOPS, 4),
+                note="parity mode: v_mfma_f32_16x16x4_f32 everywhere, float32 storage; same workload and launch mode")
+
+
+def measure_infer(batch, size, precision, steps, warmup, repeats):
+    """BASELINE config 5's core: eval-mode generator forward (BatchNorm as an affine epilogue), one captured hipGraph,
+    inputs resident.  -> (tiles/s, seconds per replay, repeats, engine, ctx, packed input)"""
+    import torch
+    import pfa_gan
+    from pfa_gan import kernels as K
+    torch.manual_seed(0)
+    gen = pfa_gan.UNetGenerator(3, 3).cuda().set_precision(precision).eval()
+    eng = gen.engine()
+    eng.refresh_shadows(force=True)
+    ctx = eng.new_ctx()
+    ctx.pin()
+    x = torch.rand((batch, 3, size, size), device="cuda") * 2 - 1
+    xh = K.pack_nhwc(x, eng.dtype)
+    for _ in range(3):
+        eng.forward(xh, ctx, train=False)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eng.forward(xh, ctx, train=False)
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    reps = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t0)
+    dt = statistics.median(reps)
+    return batch * steps / dt, dt / steps, reps, eng, ctx, xh
+
+
+def infer_leg(args, batch=64, steps=20, warmup=5):
+    """-> dict for the training line's "infer" key (config 5 at batch 64; `--mode infer` is the full line)."""
+    tiles, per, _, _, _, _ = measure_infer(batch, args.size, args.precision, steps, warmup, 3)
+    peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    flop_tile = FLOP_PER_TILE.get(args.size, 0)
+    return dict(value=round(tiles, 1), unit="tiles/s", batch=batch, ms_per_batch=round(1e3 * per, 3), steps=steps,
+                dtype=args.precision, algorithmic_tflops=round(tiles * flop_tile / 1e12, 2),
+                frac_of_peak=round(tiles * flop_tile / 1e12 / peak, 4),
+                workload=f"UNetGenerator eval forward (generate_synthetic_data.py:55-68), {args.size}x{args.size}, hipGraph "
+                         f"replay, inputs resident")
+
+
 # ----------------------------------------------------------------------------------------------------- inference (config 5)
 def infer_main(args):
     """BASELINE config 5: eval-mode generator forward over synthetic 256x256 tiles, hipGraph-captured, one GPU."""
@@ -297,31 +379,8 @@ def infer_main(args):
     from pfa_gan import _lib, kernels as K
     torch.cuda.set_device(0)
     lib = _lib.lib()
-    torch.manual_seed(0)
-    gen = pfa_gan.UNetGenerator(3, 3).cuda().set_precision(args.precision).eval()
-    eng = gen.engine()
-    eng.refresh_shadows(force=True)
-    ctx = eng.new_ctx()
-    x = torch.rand((args.batch, 3, args.size, args.size), device="cuda") * 2 - 1
-    xh = K.pack_nhwc(x, eng.dtype)
-    for _ in range(3):
-        eng.forward(xh, ctx, train=False)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        eng.forward(xh, ctx, train=False)
-    for _ in range(args.warmup):
-        graph.replay()
-    torch.cuda.synchronize()
-    reps = []
-    for _ in range(max(1, args.repeats)):
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            graph.replay()
-        torch.cuda.synchronize()
-        reps.append(time.perf_counter() - t0)
-    dt = statistics.median(reps)
-    tiles = args.batch * args.steps / dt
+    tiles, dt_step, reps, eng, ctx, xh = measure_infer(args.batch, args.size, args.precision, args.steps, args.warmup, args.repeats)
+    dt = dt_step * args.steps
     peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     flop_tile = FLOP_PER_TILE.get(args.size, 0)
     out = {
@@ -396,11 +455,13 @@ def main():
         trainer.Dn.refresh_shadows(force=True)
 
     gsrc = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    pool = []
+    pool, pool_src = [], []
     for _ in range(8):                               # distinct batches, already packed: resident in HBM
         a = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
         b = torch.rand((args.batch, 3, args.size, args.size), device="cuda", generator=gsrc) * 2 - 1
         pool.append((trainer.pack(a), trainer.pack(b)))
+        if len(pool_src) < 2:
+            pool_src.append((a, b))                  # (float32 sources of two batches: the fp32 leg packs them itself)
     torch.cuda.synchronize()                         # resident: every batch is complete before the first step
 
     def barrier():
@@ -456,8 +517,28 @@ def main():
         if flop_pair:
             tf = value * flop_pair / 1e12 / world
             out["step_mfma"] = {"algorithmic_tflops_per_gpu": round(tf, 2), "frac_of_peak": round(tf / peak, 4)}
+        bpp = BYTES_PER_PAIR.get((args.size, args.batch))
+        if bpp and args.precision == "bf16":
+            gbs = value / world * bpp / 1e9
+            out["step_hbm"] = {"algorithmic_bytes_per_step": round(bpp * args.batch), "achieved": round(gbs, 1), "unit": "GB/s",
+                               "peak": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4),
+                               "note": "SURVEY 8(d) ideal-fusion bytes per img-pair x pairs/s: the step sits on the ridge, "
+                                       "so both the MFMA and the HBM fraction are reported"}
         if roof is not None:
             out["roofline"] = roof
+        if world == 1 and not args.no_extras and args.precision == "bf16" and args.size == 256:
+            # extra legs, AFTER the headline's timed region and roofline pass, each bounded to a fraction of a second of GPU
+            # time: the parity mode on the same workload, and BASELINE config 5
+            del trainer
+            torch.cuda.synchronize()
+            try:
+                out["fp32"] = fp32_leg(args, pool_src)
+            except Exception as e:                   # an extra leg never costs the headline line
+                out["fp32"] = {"value": None, "error": repr(e)[:300]}
+            try:
+                out["infer"] = infer_leg(args)
+            except Exception as e:
+                out["infer"] = {"value": None, "error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline and args.size == 256:
             out["cpu_baseline"] = cpu_baseline_isolated(args.size, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -336,10 +336,15 @@ __global__ __launch_bounds__(256) void k_logit_wgrad_reduce(const float* __restr
 
 }  // namespace
 
+static constexpr size_t LOGIT_LDS_MAX = 159 * 1024;
+static size_t logit_wgrad_lds(int wd) { return (size_t)7 * (wd + 4) * 4 + (size_t)4 * 16 * 512 * 4; }
+
 extern "C" int pfa_logit_supported(int dtype, int c, int ld, int h, int w) {
     // (the thread mappings are built on 512 channels = 128 chunks of 4: ndf * 8 of models.py:232-241 at the default ndf)
-    return dtype == PFA_BF16 && c == 512 && ld >= 8 && ld % 8 == 0 && h >= 2 && w >= 2 && w <= 4096 && pfa_knob(3) != 1 &&
-           pfa_knob(3) != 3;
+    // (the width bound is the weight-gradient kernel's LDS budget, see pfa_logit_wgrad: the engine routes all three passes of
+    // the layer on this predicate alone, so a map too wide for one of them must not take the others either)
+    return dtype == PFA_BF16 && c == 512 && ld >= 8 && ld % 8 == 0 && h >= 2 && w >= 2 && logit_wgrad_lds(w) <= LOGIT_LDS_MAX &&
+           pfa_knob(3) != 1 && pfa_knob(3) != 3;
 }
 
 static int logit_common(LogitK& k, int nb, int h, int w, int c, int ld) {
@@ -394,8 +399,8 @@ extern "C" int pfa_logit_wgrad(const void* dlogits, int ld, const void* x, float
     if (int rc = logit_common(k, nb, h, wd, c, ld)) return rc;
     k.dl = (const char*)dlogits; k.x = (const char*)x; k.dw = dw; k.db = db; k.wslab = slab;
     k.rgroups = (h + 3) / 4;
-    const size_t lds = (size_t)7 * (wd + 4) * 4 + (size_t)4 * 16 * 512 * 4;
-    PFA_REQUIRE(lds <= 159 * 1024, "pfa_logit_wgrad: image too wide");
+    const size_t lds = logit_wgrad_lds(wd);
+    PFA_REQUIRE(lds <= LOGIT_LDS_MAX, "pfa_logit_wgrad: image too wide");
     static std::atomic<size_t> attr_lds{0};      // (the kernel also has a few static bytes: ask for what is used)
     if (attr_lds.load(std::memory_order_relaxed) < lds) {
         const hipError_t e = hipFuncSetAttribute((const void*)k_logit_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -650,12 +650,12 @@ bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int sp
     if (cin % 64 || n % 64 || hout < 1 || wout < 1) return false;
     const int tiles = nb * ((hout + TY - 1) / TY) * ((wout + TX - 1) / TX);
     int b = 0, sk = 1;
-    // (knob 10: the threshold, 192.  At 128, c4's input gradient runs un-sliced on 128 workgroups with the fused BatchNorm
-    // backward in its own epilogue - no float32 partial planes (33.5 MB written and re-read), no finish launch: inside the
-    // three-stream step that measured 0.7 % faster (3.306 vs 3.329 ms, same box), because the other streams use the idle half
-    // of the chip; alone on the GPU the launch takes 113 us instead of 60 + 12, which is what the one-stream roofline
-    // measurement of bench.py sees.  Kept at 192: the gain is inside the box-to-box noise.)
-    if (n % 128 == 0 && (long long)tiles * (n / 128) >= (pfa_knob(10) > 0 ? pfa_knob(10) : 192)) b = 128;
+    // (knob 10: the threshold, 128.  c4's input gradient then runs un-sliced on 128 workgroups with the fused BatchNorm
+    // backward in its own epilogue - no float32 partial planes (33.5 MB written and re-read), no finish launch.  Inside the
+    // three-stream step that is faster (round 2: 3.306 vs 3.329 ms; round 3, three same-box pairs: 3.044 vs 3.065 ms), because
+    // the other streams use the idle half of the chip; alone on the GPU the launch takes 113 us instead of 60 + 12, which is
+    // what a one-stream kernel trace shows.  The timed step decides: 128; 192 restores the K-sliced plan.)
+    if (n % 128 == 0 && (long long)tiles * (n / 128) >= (pfa_knob(10) > 0 ? pfa_knob(10) : 128)) b = 128;
     else if ((long long)tiles * (n / 64) >= 192 && pfa_knob(3) == 7) b = 64;          // knob 3 = 7 only: measured slower (below)
     else if (n % 128 == 0) {
         b = 128;

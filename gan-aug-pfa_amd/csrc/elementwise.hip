@@ -293,6 +293,205 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* dy, const T* __re
     }
 }
 
+// ------------------------------------------------------------------ BatchNorm: statistics finished by their consumer
+// k_bn_act_stats / k_bn_bwd_apply_stats fold the coefficient launch (k_bn_finalize / k_bn_bwd_finalize: a dependent ~5 us
+// launch on the critical chain of every BatchNorm layer, forward and backward) into the prologue of the pass that applies
+// the coefficients.  A workgroup owns a group of CG channels (64, or all of them when the layer has fewer) x a run of rows:
+// it sums the per-tile partials of ITS channels - every workgroup of a channel group in the same fixed order, hence to the
+// same bits; no cross-workgroup hand-off - and the workgroups of row block 0 publish the coefficients the backward pass reads
+// later (and the running statistics).  Order per channel: ST_LANES virtual lanes, lane l adds tiles l, l + ST_LANES, ... in
+// ascending order (double), then a halving tree over the lanes.
+constexpr int ST_LANES = 16, ST_CG = 64, ST_UNROLL = 8;
+
+// -> sums of a[tile][ch] and b[tile][ch] over the tiles for the cg channels from ch0, left in sh[0][0][.] / sh[1][0][.]
+__device__ __forceinline__ void group_tile_sums(const float* __restrict__ a, const float* __restrict__ b, int ntiles, int c,
+                                                int ch0, int cg, double (*sh)[ST_LANES][ST_CG]) {
+    const int quads = cg >> 2, tid = threadIdx.x;
+    const int quad = tid % quads, tl = tid / quads;
+    const bool active = tl < ST_LANES;
+    if (active) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+        const float* pa = a + ch0 + 4 * quad;
+        const float* pb = b + ch0 + 4 * quad;
+        for (int t0 = tl; t0 < ntiles; t0 += ST_LANES * ST_UNROLL) {
+            f32x4 av[ST_UNROLL], bv[ST_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ST_UNROLL; ++u) {           // all loads of a round in flight: each is a trip past the L2
+                const int t = t0 + u * ST_LANES;
+                if (t < ntiles) {
+                    av[u] = *(const f32x4*)(pa + (size_t)t * c);
+                    bv[u] = *(const f32x4*)(pb + (size_t)t * c);
+                } else {
+                    av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    bv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < ST_UNROLL; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[e] += (double)av[u][e]; q[e] += (double)bv[u][e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sh[0][tl][4 * quad + e] = s[e]; sh[1][tl][4 * quad + e] = q[e]; }
+    }
+    __syncthreads();
+    for (int off = ST_LANES / 2; off > 0; off >>= 1) {
+        if (active && tl < off) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sh[0][tl][4 * quad + e] += sh[0][tl + off][4 * quad + e];
+                sh[1][tl][4 * quad + e] += sh[1][tl + off][4 * quad + e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// grid (row blocks, channel groups).  Rows of a group are 16-byte chunks x cg/CH; a lane keeps one chunk column.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw, int64_t rows, int c, int cg,
+                                                      const float* __restrict__ psum, const float* __restrict__ psq,
+                                                      int ntiles, double count, const float* gamma, const float* beta,
+                                                      float eps, float momentum, int repeats, float* running_mean,
+                                                      float* running_var, int64_t* nbt, float* scale, float* shift,
+                                                      float* mean_out, float* invstd_out, float slope, T* out_l, T* out_r) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ double sh[2][ST_LANES][ST_CG];
+    __shared__ float cf[2][ST_CG];
+    const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
+    const bool pub = blockIdx.x == 0;                   // this workgroup publishes its group's coefficients
+    const bool fin = tid < cg;
+    if (pub && blockIdx.y == 0 && tid == 0 && nbt) *nbt += repeats;
+    float g32 = 1.f, b32 = 0.f, rm32 = 0.f, rv32 = 0.f;    // fetched ahead of the reduction (see k_bn_finalize)
+    if (fin) {
+        if (gamma) g32 = gamma[ch0 + tid];
+        if (beta) b32 = beta[ch0 + tid];
+        if (pub && running_mean) { rm32 = running_mean[ch0 + tid]; rv32 = running_var[ch0 + tid]; }
+    }
+    group_tile_sums(psum, psq, ntiles, c, ch0, cg, sh);
+    if (fin) {
+        const double s = sh[0][0][tid], q = sh[1][0][tid];
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double invstd = 1.0 / sqrt(var + (double)eps);
+        const double g = g32, b = b32;
+        const float sc = (float)(g * invstd), sf = (float)(b - mean * g * invstd);
+        cf[0][tid] = sc;
+        cf[1][tid] = sf;
+        if (pub) {
+            const int ch = ch0 + tid;
+            scale[ch] = sc;
+            shift[ch] = sf;
+            if (mean_out) mean_out[ch] = (float)mean;
+            if (invstd_out) invstd_out[ch] = (float)invstd;
+            if (running_mean && repeats > 0) {
+                const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                double rm = rm32, rv = rv32;
+                for (int r = 0; r < repeats; ++r) {
+                    rm = (1.0 - momentum) * rm + momentum * mean;
+                    rv = (1.0 - momentum) * rv + momentum * unb;
+                }
+                running_mean[ch] = (float)rm;
+                running_var[ch] = (float)rv;
+            }
+        }
+    }
+    __syncthreads();
+    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
+    float sc[CH], sf[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { sc[e] = cf[0][col * CH + e]; sf[e] = cf[1][col * CH + e]; }
+    const size_t coff = (size_t)ch0 + (size_t)col * CH;
+    const int64_t stride = (int64_t)gridDim.x * rpp;
+    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
+    auto emit = [&](const Chunk<T>& x, int64_t r) {
+        Chunk<T> l, rr;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            const float y = x.v[e] * sc[e] + sf[e];
+            l.v[e] = y >= 0.f ? y : y * slope;
+            rr.v[e] = y > 0.f ? y : 0.f;
+        }
+        if (out_l) l.store(out_l + (size_t)r * c + coff);
+        if (out_r) rr.store(out_r + (size_t)r * c + coff);
+    };
+    for (; row + 3 * stride < rows; row += 4 * stride) {     // four row passes in flight per lane
+        Chunk<T> x0, x1, x2, x3;
+        x0.load(raw + (size_t)row * c + coff);
+        x1.load(raw + (size_t)(row + stride) * c + coff);
+        x2.load(raw + (size_t)(row + 2 * stride) * c + coff);
+        x3.load(raw + (size_t)(row + 3 * stride) * c + coff);
+        emit(x0, row); emit(x1, row + stride); emit(x2, row + 2 * stride); emit(x3, row + 3 * stride);
+    }
+    for (; row < rows; row += stride) {
+        Chunk<T> x;
+        x.load(raw + (size_t)row * c + coff);
+        emit(x, row);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T* __restrict__ raw, int64_t rows, int c,
+                                                            int cg, const float* __restrict__ part, int ntiles, double count,
+                                                            const float* gamma, const float* mean, const float* invstd,
+                                                            float* dgamma, float* dbeta, T* dr) {
+    constexpr int CH = ElemTraits<T>::CH;
+    __shared__ double sh[2][ST_LANES][ST_CG];
+    __shared__ float cf[3][ST_CG];
+    const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
+    const bool pub = blockIdx.x == 0, fin = tid < cg;
+    float g32 = 1.f, is32 = 0.f, mu32 = 0.f, dg32 = 0.f, db32 = 0.f;
+    if (fin) {
+        const int ch = ch0 + tid;
+        if (gamma) g32 = gamma[ch];
+        is32 = invstd[ch];
+        mu32 = mean[ch];
+        if (pub && dgamma) dg32 = dgamma[ch];
+        if (pub && dbeta) db32 = dbeta[ch];
+    }
+    group_tile_sums(part, part + (size_t)ntiles * c, ntiles, c, ch0, cg, sh);
+    if (fin) {
+        const double sdy = sh[0][0][tid], sdyx = sh[1][0][tid];
+        if (pub) {
+            if (dgamma) dgamma[ch0 + tid] = dg32 + (float)sdyx;     // gradients accumulate into a zeroed arena
+            if (dbeta) dbeta[ch0 + tid] = db32 + (float)sdy;
+        }
+        const double g = g32, is = is32, mu = mu32, s = g * is;
+        cf[0][tid] = (float)s;
+        cf[1][tid] = (float)(-s * is * sdyx / count);
+        cf[2][tid] = (float)(-s * sdy / count + s * is * mu * sdyx / count);
+    }
+    __syncthreads();
+    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
+    float ka[CH], kb[CH], kc[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) { ka[e] = cf[0][col * CH + e]; kb[e] = cf[1][col * CH + e]; kc[e] = cf[2][col * CH + e]; }
+    const size_t coff = (size_t)ch0 + (size_t)col * CH;
+    const int64_t stride = (int64_t)gridDim.x * rpp;
+    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
+    auto emit = [&](const Chunk<T>& d, const Chunk<T>& x, int64_t r) {
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) o.v[e] = ka[e] * d.v[e] + kb[e] * x.v[e] + kc[e];
+        o.store(dr + (size_t)r * c + coff);
+    };
+    for (; row + stride < rows; row += 2 * stride) {
+        Chunk<T> d0, x0, d1, x1;
+        d0.load(dy + (size_t)row * c + coff);
+        x0.load(raw + (size_t)row * c + coff);
+        d1.load(dy + (size_t)(row + stride) * c + coff);
+        x1.load(raw + (size_t)(row + stride) * c + coff);
+        emit(d0, x0, row); emit(d1, x1, row + stride);
+    }
+    for (; row < rows; row += stride) {
+        Chunk<T> d, x;
+        d.load(dy + (size_t)row * c + coff);
+        x.load(raw + (size_t)row * c + coff);
+        emit(d, x, row);
+    }
+}
+
 // ------------------------------------------------------------------ losses
 __device__ __forceinline__ float block_sum(float v, float* sh) {
 #pragma unroll
@@ -664,6 +863,71 @@ extern "C" int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const
                hipLaunchKernelGGL(k_bn_act<float>, dim3(grid), dim3(256), 0, (hipStream_t)s,
                                   (const float*)raw, nchunks, cpr, scale, shift, slope, (float*)out_l, (float*)out_r));
     PFA_LAUNCHED("k_bn_act");
+    return 0;
+}
+
+// Channel group and grid of the statistics-in-the-prologue passes; cg = 0: shape not built (callers keep the two launches).
+static int stats_group(int c, int dtype) {
+    const int ch = pfa_ch(dtype);
+    if (c % ch) return 0;
+    if (c % ST_CG == 0) return ST_CG;
+    if (c < ST_CG && c % 4 == 0 && 256 % (c / ch) == 0) return c;
+    return 0;
+}
+static dim3 stats_grid(int64_t rows, int c, int cg, int dtype, int ntiles) {
+    const int rpp = 256 / (cg / pfa_ch(dtype)), groups = c / cg;
+    const int64_t passes = (rows + rpp - 1) / rpp;
+    // every workgroup re-reads ntiles x cg x 2 floats of partials: keep that under ~64 MB per launch
+    int64_t cap = ((int64_t)64 << 20) / ((int64_t)ntiles * cg * 8);
+    if (cap > 2048) cap = 2048;
+    int64_t gx = cap / groups;
+    if (gx > (passes + 3) / 4) gx = (passes + 3) / 4;       // ~4 row passes per lane
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)groups);
+}
+
+extern "C" int pfa_bn_stats_fused_supported(int dtype, int c, int ntiles) {
+    const int lim = pfa_knob(14) > 0 ? pfa_knob(14) : 256;
+    return (dtype == PFA_BF16 || dtype == PFA_F32) && pfa_knob(14) >= 0 && ntiles > 0 && ntiles <= lim && stats_group(c, dtype) > 0;
+}
+
+extern "C" int pfa_bn_act_stats(const void* raw, int64_t rows, int c, int dtype, const float* psum, const float* psq,
+                                int ntiles, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                int repeats, float* running_mean, float* running_var, int64_t* nbt, float* scale,
+                                float* shift, float* mean, float* invstd, float slope, void* out_l, void* out_r,
+                                pfa_stream s) {
+    PFA_REQUIRE(raw && psum && psq && scale && shift && rows > 0 && ntiles > 0 && count > 0 && (out_l || out_r),
+                "pfa_bn_act_stats: bad arguments");
+    const int cg = stats_group(c, dtype);
+    PFA_REQUIRE(cg > 0, "pfa_bn_act_stats: channel count %d not built (pfa_bn_stats_fused_supported)", c);
+    const dim3 grid = stats_grid(rows, c, cg, dtype, ntiles);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bn_act_stats<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)raw, rows, c, cg,
+                                  psum, psq, ntiles, count, gamma, beta, eps, momentum, repeats, running_mean, running_var,
+                                  nbt, scale, shift, mean, invstd, slope, (bf16_t*)out_l, (bf16_t*)out_r),
+               hipLaunchKernelGGL(k_bn_act_stats<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)raw, rows, c, cg,
+                                  psum, psq, ntiles, count, gamma, beta, eps, momentum, repeats, running_mean, running_var,
+                                  nbt, scale, shift, mean, invstd, slope, (float*)out_l, (float*)out_r));
+    PFA_LAUNCHED("k_bn_act_stats");
+    return 0;
+}
+
+extern "C" int pfa_bn_bwd_apply_stats(const void* dy, const void* raw, int64_t rows, int c, int dtype, const float* part,
+                                      int ntiles, double count, const float* gamma, const float* mean, const float* invstd,
+                                      float* dgamma, float* dbeta, void* dr, pfa_stream s) {
+    PFA_REQUIRE(dy && raw && part && mean && invstd && dr && rows > 0 && ntiles > 0 && count > 0,
+                "pfa_bn_bwd_apply_stats: bad arguments");
+    const int cg = stats_group(c, dtype);
+    PFA_REQUIRE(cg > 0, "pfa_bn_bwd_apply_stats: channel count %d not built (pfa_bn_stats_fused_supported)", c);
+    const dim3 grid = stats_grid(rows, c, cg, dtype, ntiles);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(k_bn_bwd_apply_stats<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy,
+                                  (const bf16_t*)raw, rows, c, cg, part, ntiles, count, gamma, mean, invstd, dgamma, dbeta,
+                                  (bf16_t*)dr),
+               hipLaunchKernelGGL(k_bn_bwd_apply_stats<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dy,
+                                  (const float*)raw, rows, c, cg, part, ntiles, count, gamma, mean, invstd, dgamma, dbeta,
+                                  (float*)dr));
+    PFA_LAUNCHED("k_bn_bwd_apply_stats");
     return 0;
 }
 

@@ -90,6 +90,12 @@ PROTOTYPES = {
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_eval_coeffs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_act": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "pfa_bn_stats_fused_supported": (c_int, [c_int, c_int, c_int]),
+    "pfa_bn_act_stats": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                 c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_float, c_void_p, c_void_p, c_void_p]),
+    "pfa_bn_bwd_apply_stats": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pfa_bn_bwd_reduce": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "pfa_bn_bwd_tiles": (c_int, [c_int64, c_int, c_int]),
@@ -199,9 +205,13 @@ class _Proxy:
         rec = self._rec
 
         def call(*args):
+            # by-reference argument blocks are copied BEFORE the call: entry points write results into them (pfa_gather_gemm:
+            # the planes actually written, the number of statistics tiles), and a replay must pass the REQUEST again, not
+            # the previous call's answers
+            noted = rec.snapshot(name, args)
             rc = fn(*args)
             if rc == 0:
-                rec.note_call(name, idx, args)
+                rec.note_call(name, idx, noted)
             return rc
         return call
 
@@ -248,21 +258,25 @@ class Recorder:
             cls._structs[name] = st
         return st
 
-    def note_call(self, name, idx, args):
+    def snapshot(self, name, args):
+        """The call's arguments as they will be replayed: by-reference blocks (ctypes.byref(x)) copied as they are NOW."""
         st = self._arg_struct(name)()
+        keep = [st]
         for i, (t, v) in enumerate(zip(PROTOTYPES[name][1], args)):
             if isinstance(t, type) and issubclass(t, ctypes._Pointer):
-                if v is None:
-                    v = None
-                else:
+                if v is not None:
                     obj = getattr(v, "_obj", None)          # ctypes.byref(x)
                     if obj is None:
                         raise PfaError(f"{name}: argument {i} cannot be recorded (pass ctypes.byref of a ctypes object)")
                     copy = type(obj).from_buffer_copy(obj)
-                    self.keep.append(copy)
+                    keep.append(copy)
                     v = ctypes.addressof(copy)
             setattr(st, f"a{i}", v)
-        self.keep.append(st)
+        return st, keep
+
+    def note_call(self, name, idx, noted):
+        st, keep = noted
+        self.keep += keep
         self.ops.append(ReplayOp(OP_CALL, idx, ctypes.addressof(st), None))
 
     def note_record(self, event, stream):

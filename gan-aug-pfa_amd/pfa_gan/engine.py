@@ -103,17 +103,29 @@ class Ctx:
     def __init__(self, device):
         self.device = device
         self._t = {}
-        self._retired = []      # replaced buffers stay alive: a captured hipGraph may still launch kernels on them
+        self.pinned = False     # set by whoever captures a hipGraph / records a launch list on these buffers (pin())
+        self._shelf = {}        # pinned contexts: (name, shape, dtype) -> buffer of a shape that is not the current one
         self.v = {}
+
+    def pin(self):
+        """A hipGraph or launch list now holds these buffers' addresses - or other streams use them without telling the
+        allocator: from here on a buffer that is replaced (a batch of another shape between two replays) is shelved under
+        its shape and taken up again when that shape returns, never handed back to the allocator.  Memory is bounded by the
+        number of distinct shapes, not by the number of shape changes."""
+        self.pinned = True
 
     def buf(self, name, shape, dtype):
         t = self._t.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            if t is not None:
+        shape = tuple(shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            if t is not None and self.pinned:
                 # a batch of another shape (a ragged last batch between two hipGraph replays): the graph keeps launching
-                # on the old buffer, so it must not go back to the allocator; shapes alternate at most a few times
-                self._retired.append(t)
-            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+                # on the old buffer.  An eager context (eval forwards, inference on tiles of changing size: everything on
+                # the current stream) just drops it.
+                self._shelf[(name, tuple(t.shape), t.dtype)] = t
+            t = self._shelf.pop((name, shape, dtype), None) if self.pinned else None
+            if t is None:
+                t = torch.zeros(shape, dtype=dtype, device=self.device)
             self._t[name] = t
         return t
 
@@ -331,6 +343,24 @@ class _Engine:
                 ctx.v[tag + ".evalkey"] = key
         return scale, shift
 
+    def _bn_act_train(self, L, ctx, tag, raw, st, count, repeats, out_l, out_r):
+        """Training-mode BatchNorm of a conv output whose per-tile partial sums `st` the convolution's epilogue wrote:
+        coefficients + running buffers + normalise / activate.  One launch (every workgroup finishes the statistics of
+        its own channel group in its prologue) where the shape allows it, else bn_finalize + bn_act."""
+        psum, psq, nt = st
+        if not K.bn_stats_fused_ok(raw.dtype, L.cout, nt) or raw.shape[3] != L.cout:
+            scale, shift = self._bn_coeffs(L, ctx, tag, st, count, True, repeats)
+            K.bn_act(raw, scale, shift, out_l, out_r)
+            return
+        c, f32, bn = L.cout, torch.float32, L.bn
+        track = bn.track_running_stats and bn.running_mean is not None
+        self.bn_epoch += 1          # scale/shift now hold batch statistics; the running statistics move
+        K.bn_act_stats(raw, psum, psq, nt, count, bn.weight, bn.bias, bn.running_mean if track else None,
+                       bn.running_var if track else None, bn.num_batches_tracked if track else None,
+                       ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32),
+                       ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32), out_l, out_r,
+                       repeats=repeats if track else 0)
+
     def _conv_bn_act(self, mode, srcs, L, ctx, tag, raw, grid, train, repeats, out_l, out_r):
         """raw = conv(srcs); BatchNorm (batch statistics when train); out_l = LeakyReLU(y), out_r = ReLU(y) (either may be
         None).  A K-sliced launch on a small map is finished over the whole batch in one launch (K.finish_bn_fwd) instead
@@ -345,6 +375,9 @@ class _Engine:
                             ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32))
             return
         st = K.gather_gemm(mode, srcs, L.w_fwd, L.cout, [raw], grid, self.ws, stats=train)
+        if train:
+            self._bn_act_train(L, ctx, tag, raw, st, count, repeats, out_l, out_r)
+            return
         scale, shift = self._bn_coeffs(L, ctx, tag, st, count, train, repeats)
         K.bn_act(raw, scale, shift, out_l, out_r)
 
@@ -373,9 +406,19 @@ class _Engine:
         scale, shift = ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32)
         mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
         part, nt = K.bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, self.ws_cur)
-        coef = ctx.buf(tag + ".coef", (3 * c,), f32)
+        return self._bn_bwd_finish(L, ctx, tag, raw, count, garena, dy, part, nt, param_grads)
+
+    def _bn_bwd_finish(self, L, ctx, tag, raw, count, garena, dy, part, nt, param_grads):
+        """dy (in place) -> gradient of the conv output, from the partial sums of dy and dy * xhat; dgamma / dbeta.  One
+        launch where the shape allows it (see _bn_act_train), else bn_bwd_finalize + bn_bwd_apply."""
+        f32, c = torch.float32, L.cout
+        mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
         dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
         dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
+        if K.bn_stats_fused_ok(raw.dtype, c, nt) and raw.shape[3] == c:
+            K.bn_bwd_apply_stats(dy, raw, part, nt, count, L.bn.weight, mean, invstd, dgamma, dbeta, dy)
+            return dy
+        coef = ctx.buf(tag + ".coef", (3 * c,), f32)
         K.bn_bwd_finalize(part, nt, c, count, L.bn.weight, mean, invstd, dgamma, dbeta, coef)
         K.bn_bwd_apply(dy, raw, coef, dy)
         return dy
@@ -395,14 +438,7 @@ class _Engine:
         if L.bn is None:
             return dy
         part, _, nt = st
-        f32, c = torch.float32, L.cout
-        coef = ctx.buf(tag + ".coef", (3 * c,), f32)
-        dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
-        dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
-        K.bn_bwd_finalize(part, nt, c, count, L.bn.weight, ctx.buf(tag + ".mean", (c,), f32),
-                          ctx.buf(tag + ".invstd", (c,), f32), dgamma, dbeta, coef)
-        K.bn_bwd_apply(dy, raw, coef, dy)
-        return dy
+        return self._bn_bwd_finish(L, ctx, tag, raw, count, garena, dy, part, nt, param_grads)
 
     def _act_backward(self, ctx, tag, act_out, g1, act1, g2=None, act2=K.ACT_NONE):
         """Conv output without a norm: its gradient is act'(.)*g, and sign(act_out) == sign(pre-activation)."""
@@ -672,9 +708,12 @@ class DiscriminatorEngine(_Engine):
             else:
                 raw = ctx.buf(f"c{i}.raw", shape, dt)
                 st = K.gather_gemm(mode, a, L.w_fwd, L.cout, [raw], (B, ho, wo), self.ws, bias=L.b, stats=train)
-                scale, shift = self._bn_coeffs(L, ctx, f"c{i}", st, B * ho * wo, train, 1)
                 out = ctx.buf(f"c{i}.a", shape, dt)
-                K.bn_act(raw, scale, shift, out, None)
+                if train:
+                    self._bn_act_train(L, ctx, f"c{i}", raw, st, B * ho * wo, 1, out, None)
+                else:
+                    scale, shift = self._bn_coeffs(L, ctx, f"c{i}", st, B * ho * wo, train, 1)
+                    K.bn_act(raw, scale, shift, out, None)
             ctx.v["a"][i] = out
             a, h, w = [out], ho, wo
         return a[0]

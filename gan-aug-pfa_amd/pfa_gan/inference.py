@@ -31,6 +31,7 @@ class TilePipeline:
         eng = gen.engine()
         eng.refresh_shadows(force=False)
         self.eng, self.ctx = eng, eng.new_ctx()
+        self.ctx.pin()                           # the captured graphs below hold these buffers' addresses
         self.main = torch.cuda.current_stream(dev)
         self.copy = torch.cuda.Stream(device=dev)
         self.x_pin = [torch.empty(self.shape, dtype=torch.float32).pin_memory() for _ in range(2)]

@@ -142,6 +142,7 @@ def choose_splitk(mode, M, n, ctot, dtype):
 
 
 import os as _os
+BN_STATS_FUSED = _os.environ.get("PFA_BN_STATS_FUSED", "1") != "0"   # A/B switch: coefficient launches folded into their consumers
 FUSE_BWD = _os.environ.get("PFA_FUSE_BWD", "1") != "0"     # A/B switch for the fused dgrad epilogue
 IMAGE_DGRAD_FUSE = _os.environ.get("PFA_IMAGE_DGRAD_FUSE", "1") != "0"   # A/B switch: fused backward on the image-side input gradient
 FUSE_SPLIT = _os.environ.get("PFA_FUSE_SPLIT", "1") != "0"  # ... and for fusing it into the finish pass of K-sliced launches
@@ -419,6 +420,28 @@ def bn_act(raw, scale, shift, out_l=None, out_r=None):
     _require_cuda(raw)
     check(lib().pfa_bn_act(ptr(raw), rows_of(raw), raw.shape[3], dt_code(raw.dtype), ptr(scale), ptr(shift), SLOPE,
                            ptr(out_l), ptr(out_r), stream()), "pfa_bn_act")
+
+
+def bn_stats_fused_ok(dtype, c, ntiles):
+    """Can the coefficient launch be folded into the pass that applies it (bn_act_stats / bn_bwd_apply_stats)?"""
+    return BN_STATS_FUSED and bool(lib().pfa_bn_stats_fused_supported(dt_code(dtype), c, ntiles))
+
+
+def bn_act_stats(raw, psum, psq, ntiles, count, gamma, beta, running_mean, running_var, nbt, scale, shift, mean, invstd,
+                 out_l=None, out_r=None, repeats=1):
+    """bn_finalize + bn_act in one launch (the statistics are finished in the prologue of every workgroup)."""
+    _require_cuda(raw)
+    check(lib().pfa_bn_act_stats(ptr(raw), rows_of(raw), raw.shape[3], dt_code(raw.dtype), ptr(psum), ptr(psq), ntiles,
+                                 float(count), ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, repeats, ptr(running_mean),
+                                 ptr(running_var), ptr(nbt), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), SLOPE,
+                                 ptr(out_l), ptr(out_r), stream()), "pfa_bn_act_stats")
+
+
+def bn_bwd_apply_stats(dy, raw, part, ntiles, count, gamma, mean, invstd, dgamma, dbeta, dr):
+    """bn_bwd_finalize + bn_bwd_apply in one launch."""
+    check(lib().pfa_bn_bwd_apply_stats(ptr(dy), ptr(raw), rows_of(raw), raw.shape[3], dt_code(raw.dtype), ptr(part), ntiles,
+                                       float(count), ptr(gamma), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(dr),
+                                       stream()), "pfa_bn_bwd_apply_stats")
 
 
 def bn_bwd_reduce(raw, scale, shift, mean, invstd, g1, act1, g2, act2, dy, ws):

@@ -186,6 +186,11 @@ class GanTrainer:
         self._g_reduced = False
         dev = self.G.device
         self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
+        if overlap or use_graph:
+            # the step's side streams read and write these buffers (torch's allocator only knows the stream that allocated
+            # them), graphs and launch lists hold their addresses: a replaced buffer is shelved, not freed
+            for c in (self.gctx, self.ctx_r, self.ctx_f):
+                c.pin()
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)     # [loss_d, loss_g] of the last step
         self.loss_sums = torch.zeros(2, dtype=torch.float32, device=dev)
         self.nsteps = 0
@@ -303,7 +308,8 @@ class GanTrainer:
         K.wait_stream(main, self.side2)
         self._mark("D gradients complete")
         if bucketed_d:                       # what is left: c1 .. c3 (and D(real)'s arena, reduced above)
-            self._d_works.append(self._reduce(garena[:d_lo], ("d", 1), async_op=True))
+            if d_lo > 0:                     # (n_layers = 1: the bucket already is the whole arena)
+                self._d_works.append(self._reduce(garena[:d_lo], ("d", 1), async_op=True))
             self._d_reduced = True
         # loss_d of this step (before _ev_d_free: the next step's D(real) may overwrite its partials from there on)
         K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
@@ -483,6 +489,8 @@ class GanTrainer:
         self._listing = self.use_graph == "replay" and self.side is not None
         ready = self._ev_static if self._listing else None
         if self._graphs is None:
+            for c in (self.gctx, self.ctx_r, self.ctx_f):     # captured addresses: replaced buffers must outlive the graphs
+                c.pin()
             self._static = (torch.empty_like(xa), torch.empty_like(xb))
             sa, sb = self._static
             sa.copy_(xa)

@@ -71,10 +71,11 @@ uint64_t pfa_launch_count(void);
  * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half), 11..17 = diagnostic instantiations of the
  * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong;
  * id 8: workgroups a weight-gradient patch launch wants (0 = 128); id 9: workgroup count from which transposed
- * convolutions take four-class workgroups, id 10: 128-channel tile count below which stride-1 convolutions slice K (0 = 192); id 11: Adam grid (0 = default);
+ * convolutions take four-class workgroups, id 10: 128-channel tile count below which stride-1 convolutions slice K (0 = 128); id 11: Adam grid (0 = default);
  * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256);
  * id 13: two tap rows per workgroup in the patch weight gradient (wgrad_patch.hip): 2 = always, 3 = where its ring keeps
- * four stages (stride 1, 4x16 tile). */
+ * four stages (stride 1, 4x16 tile); id 14: partial rows up to which the BatchNorm coefficient launch is folded into the pass
+ * that applies it (pfa_bn_act_stats / pfa_bn_bwd_apply_stats; 0 = 256, -1 = never). */
 int pfa_set_knob(int id, int value);
 /* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write clock stamps per
  * workgroup: conv (uint64[workgroups][16]: 8 shader-clock stamps - entry, first fragments, K loop done, accumulators in LDS,
@@ -259,6 +260,22 @@ int pfa_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* y = scale*raw + shift (identity when scale==NULL); out_l = LeakyReLU(y), out_r = ReLU(y); either may be NULL. */
 int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const float* scale, const float* shift, float slope,
                void* out_l, void* out_r, pfa_stream s);
+/* pfa_bn_finalize + pfa_bn_act in ONE launch: every workgroup sums the per-tile partials of its own 64-channel group in
+ * its prologue (the same fixed order in every workgroup: the same bits, no hand-off between workgroups), normalises and
+ * activates its rows; the workgroups of row block 0 write scale / shift / mean / invstd (read by the backward pass) and
+ * update the running buffers `repeats` times.  Built for pfa_bn_stats_fused_supported(dtype, c, ntiles) != 0 (c a multiple
+ * of 64, or a smaller power-of-two chunk count; at most 256 partial rows: pfa_set_knob(14, limit | -1 = never)); other
+ * shapes keep the two launches.  raw is [rows][c] (unpadded rows: BatchNorm layers have c % 16 bytes == 0). */
+int pfa_bn_stats_fused_supported(int dtype, int c, int ntiles);
+int pfa_bn_act_stats(const void* raw, int64_t rows, int c, int dtype, const float* psum, const float* psq, int ntiles,
+                     double count, const float* gamma, const float* beta, float eps, float momentum, int repeats,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float* scale, float* shift,
+                     float* mean, float* invstd, float slope, void* out_l, void* out_r, pfa_stream s);
+/* pfa_bn_bwd_finalize + pfa_bn_bwd_apply in ONE launch, same scheme: dr = BatchNorm backward of dy (in place allowed),
+ * dgamma / dbeta += the channel sums (row block 0). */
+int pfa_bn_bwd_apply_stats(const void* dy, const void* raw, int64_t rows, int c, int dtype, const float* part, int ntiles,
+                           double count, const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, void* dr, pfa_stream s);
 /* dy = act1'(y)*g1 (+ act2'(y)*g2), y = scale*raw+shift; partial sums of dy and dy*xhat -> part[2][tiles][c].
  * With mean==NULL (no norm after this conv) only dy is written (then dy IS the conv-output gradient). */
 int pfa_bn_bwd_reduce(const void* raw, int64_t rows, int c, int dtype, const float* scale, const float* shift,

@@ -40,3 +40,23 @@ def test_struct_layout_matches_the_header():
     assert ctypes.sizeof(_lib.GatherArgs) == 72 + 9 * 8 + 16 + 6 * 8
     assert ctypes.sizeof(_lib.WgradArgs) == 18 * 4 + 6 * 8
     assert ctypes.sizeof(_lib.ScatterArgs) == 12 * 4 + 5 * 8          # pfa_scatter_args
+
+
+def test_asm_read_kernels_use_no_scratch():
+    """The patch kernels read LDS through inline asm into registers they name: a spilled register that is the target of an
+    in-flight asm read is saved before the data lands (silent corruption).  Every build must keep them
+    out of scratch: read from the code objects' notes (no GPU needed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.kernel_resources()
+    assert len(res) > 50, "kernel notes not found in libpfa_hip.so"
+    asm_families = ("k_conv_patch2", "k_tconv4", "k_conv_s1_inplace", "k_conv_s1_patch32", "k_wgrad_patch<", "k_wgrad_image<",
+                    "k_conv_image", "k_gemm_small")
+    checked = 0
+    for name, r in res.items():
+        if any(f in name for f in asm_families):
+            checked += 1
+            assert r.get("private_segment_fixed_size", 0) == 0 and r.get("vgpr_spill_count", 0) == 0, (name, r)
+    assert checked >= 10

@@ -104,6 +104,28 @@ def test_conv_forward(case, dtype, ws):
     close(q, (raw.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), torch.float32, name + ".psq")
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("splitk", [1, 2], ids=["gemm_epilogue", "finish_pass"])
+def test_relu_epilogue_of_an_overflowed_sum_is_zero(dtype, splitk, ws):
+    """ReLU(-inf) = 0 as torch.relu gives it (models.py:180), not -inf * 0 = NaN: a conv output that overflowed must not
+    poison what reads it.  LeakyReLU(-inf) stays -inf."""
+    n, ci, h, w, co = 1, 64, 8, 8, 16
+    x = np.abs(rnd(fill.uniform("inf.x", (n, ci, h, w)), dtype)) + 0.5
+    x[0, 3, 2, 5] = -np.inf
+    wt = np.abs(rnd(fill.uniform("inf.w", (co, ci, 4, 4), -0.25, 0.25), dtype)) + 0.125
+    raw = ops.conv2d_fwd(x, wt, None, 2)
+    assert np.isneginf(raw).any() and np.isfinite(raw).any()
+    same, _ = shadows(wt, dtype, want=("same",))
+    for act, want in ((K.ACT_RELU, ops.relu(raw)), (K.ACT_LRELU, np.where(raw > 0, raw, raw * np.float32(K.SLOPE)))):
+        out = torch.full((n, h // 2, w // 2, K.pad_ch(co, dtype)), 7.0, dtype=dtype, device="cuda")
+        K.gather_gemm(K.CONV_S2, [to_nhwc(x, dtype)], same, co, [out], (n, h // 2, w // 2), ws, act=act, splitk=splitk)
+        got = from_nhwc(out, co)
+        assert not np.isnan(got).any(), f"act {act}: NaN in the output"
+        assert np.array_equal(np.isneginf(got), np.isneginf(want))
+        fin = np.isfinite(want)
+        close(got[fin], want[fin], dtype, f"act {act}")
+
+
 PATCH_CASES = [  # name, N, Ci, H, W, Co, K slices
     ("c4_like", 2, 64, 17, 19, 128, 1),       # ragged patch rows (16 -> two 8-row tiles) and columns (18 of 32)
     ("full_width", 3, 128, 12, 33, 256, 1),   # 32 output columns: the whole patch width; two channel chunks, two n-tiles
@@ -631,6 +653,14 @@ def test_logit_layer_support():
     assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 512, 8, 31, 31) == 1
     assert lib.pfa_logit_supported(K.dt_code(torch.float32), 512, 4, 31, 31) == 0      # float32 keeps the general kernels
     assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 256, 8, 31, 31) == 0
+    # the widest map ALL THREE kernels take (the weight gradient's LDS budget bounds it): the engine routes forward, input
+    # gradient and weight gradient on this one predicate
+    assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 512, 8, 4, 1129) == 1
+    assert lib.pfa_logit_supported(K.dt_code(torch.bfloat16), 512, 8, 4, 1130) == 0
+    wide = torch.zeros((1, 4, 1129, 512), dtype=torch.bfloat16, device="cuda")
+    K.logit_wgrad(torch.zeros((1, 3, 1128, 8), dtype=torch.bfloat16, device="cuda"), wide,
+                  torch.zeros(16 * 512, device="cuda"), torch.zeros(1, device="cuda"))
+    torch.cuda.synchronize()
     x = torch.zeros((1, 4, 4, 256), dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_lib.PfaError):
         K.logit_fwd(x, x, None, torch.zeros((1, 3, 3, 8), dtype=torch.bfloat16, device="cuda"))
@@ -1035,6 +1065,93 @@ def test_batchnorm_roundtrip(dtype, ws):
     K.bn_eval_coeffs(gt, bt, rm, rv, scale, shift)
     K.bn_act(xt, scale, shift, out_l, None)
     close(from_nhwc(out_l, c), ops.leaky_relu(ops.bn_eval_fwd(x, g, b, rm2, rv2)), dtype, "eval bn+lrelu")
+
+
+STATS_FUSED_CASES = [  # name, N, C, H, W, partial rows
+    ("c16_3tiles", 3, 16, 9, 7, 3),           # fewer channels than a group: one group of 16
+    ("c64_17tiles", 2, 64, 12, 10, 17),       # one full group, more partial rows than virtual lanes
+    ("c192_130tiles", 2, 192, 24, 23, 130),   # three groups, two load rounds per lane, ragged row blocks
+    ("c128_256tiles", 1, 128, 40, 36, 256),   # the limit of the folded form
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", STATS_FUSED_CASES, ids=[c[0] for c in STATS_FUSED_CASES])
+def test_batchnorm_statistics_folded_into_their_consumers(case, dtype, ws):
+    """pfa_bn_act_stats / pfa_bn_bwd_apply_stats (coefficient launch folded into the applying pass) against the oracle's
+    BatchNorm (models.py:179,181 semantics) and against the two-launch route they replace."""
+    name, n, c, h, w, nt = case
+    x = rnd(fill.uniform(name + ".x", (n, c, h, w), -2, 3), dtype)
+    g = fill.uniform(name + ".g", (c,), 0.5, 1.5)
+    b = fill.uniform(name + ".b", (c,), -0.5, 0.5)
+    rm0 = fill.uniform(name + ".rm", (c,))
+    rv0 = fill.uniform(name + ".rv", (c,), 0.5, 2.0)
+    y, cache, rm2, rv2, nbt2 = ops.bn_train_fwd(x, g, b, rm0, rv0, 5, repeats=2)
+    xt = to_nhwc(x, dtype)
+    rows = n * h * w
+    assert K.bn_stats_fused_ok(dtype, c, nt) and not K.bn_stats_fused_ok(dtype, c, 257) and not K.bn_stats_fused_ok(dtype, 96, nt)
+    xf = torch.from_numpy(x.transpose(0, 2, 3, 1).reshape(rows, c)).cuda().double()
+    cuts = [round(i * rows / nt) for i in range(nt + 1)]          # nt row tiles of uneven length (some may be empty)
+    zero = torch.zeros(c, dtype=torch.float64, device="cuda")
+    psum = torch.stack([xf[a:e].sum(0) if e > a else zero for a, e in zip(cuts[:-1], cuts[1:])]).float().contiguous()
+    psq = torch.stack([(xf[a:e] ** 2).sum(0) if e > a else zero for a, e in zip(cuts[:-1], cuts[1:])]).float().contiguous()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gt, bt = dev(g), dev(b)
+    res = {}
+    for route in ("folded", "two_launches"):
+        rm, rv = dev(rm0), dev(rv0)
+        nbt = torch.tensor(5, dtype=torch.int64, device="cuda")
+        scale, shift, mean, invstd = (torch.full((c,), float("nan"), device="cuda") for _ in range(4))
+        out_l, out_r = torch.empty_like(xt), torch.empty_like(xt)
+        if route == "folded":
+            K.bn_act_stats(xt, psum, psq, nt, rows, gt, bt, rm, rv, nbt, scale, shift, mean, invstd, out_l, out_r, repeats=2)
+        else:
+            K.bn_finalize(psum, psq, nt, c, rows, gt, bt, rm, rv, nbt, scale, shift, mean, invstd, repeats=2)
+            K.bn_act(xt, scale, shift, out_l, out_r)
+        torch.cuda.synchronize()
+        assert int(nbt) == nbt2 == 7
+        close(rm.cpu().numpy(), rm2, torch.float32, route + " running_mean")
+        close(rv.cpu().numpy(), rv2, torch.float32, route + " running_var")
+        close(from_nhwc(out_l, c), ops.leaky_relu(y), dtype, route + " bn+lrelu")
+        close(from_nhwc(out_r, c), ops.relu(y), dtype, route + " bn+relu")
+        res[route] = (scale, shift, mean, invstd, out_l, out_r)
+    for a, e, what in zip(res["folded"], res["two_launches"], ("scale", "shift", "mean", "invstd", "out_l", "out_r")):
+        # same partials, another summation order (double): the float32 coefficients agree to the last bit or two
+        assert torch.allclose(a.float(), e.float(), rtol=2e-6 if what in ("scale", "shift", "mean", "invstd") else 1e-2, atol=1e-6), what
+    # only one output
+    only = torch.empty_like(xt)
+    scale, shift, mean, invstd = res["folded"][:4]
+    K.bn_act_stats(xt, psum, psq, nt, rows, gt, bt, None, None, None, scale, shift, mean, invstd, None, only, repeats=0)
+    assert torch.equal(only, res["folded"][5])
+    # backward
+    g1 = rnd(fill.uniform(name + ".g1", (n, c, h, w)), dtype)
+    g2 = rnd(fill.uniform(name + ".g2", (n, c, h, w)), dtype)
+    dy_ref = ops.leaky_relu_bwd(y, g1) + ops.relu_bwd(y, g2)
+    dx_ref, dg_ref, db_ref = ops.bn_train_bwd(rnd(dy_ref, dtype), g, cache)
+    dy = torch.empty_like(xt)
+    part, ntb = K.bn_bwd_reduce(xt, scale, shift, mean, invstd, to_nhwc(g1, dtype), K.ACT_LRELU, to_nhwc(g2, dtype),
+                                K.ACT_RELU, dy, ws)
+    assert K.bn_stats_fused_ok(dtype, c, ntb)
+    lo = torch.float32 if dtype == torch.float32 else torch.bfloat16
+    outs = {}
+    for route in ("folded", "two_launches"):
+        dgamma, dbeta = torch.ones(c, device="cuda"), torch.full((c,), 2.0, device="cuda")     # gradients accumulate
+        dr = torch.empty_like(xt)
+        if route == "folded":
+            K.bn_bwd_apply_stats(dy, xt, part, ntb, rows, gt, mean, invstd, dgamma, dbeta, dr)
+        else:
+            coef = torch.empty(3 * c, device="cuda")
+            K.bn_bwd_finalize(part, ntb, c, rows, gt, mean, invstd, dgamma, dbeta, coef)
+            K.bn_bwd_apply(dy, xt, coef, dr)
+        torch.cuda.synchronize()
+        close(dgamma.cpu().numpy() - 1.0, dg_ref, lo, route + " dgamma")
+        close(dbeta.cpu().numpy() - 2.0, db_ref, lo, route + " dbeta")
+        close(from_nhwc(dr, c), dx_ref, dtype, route + " dx")
+        outs[route] = dr
+    assert torch.allclose(outs["folded"].float(), outs["two_launches"].float(), rtol=1e-2, atol=1e-5)
+    # in place on dy, without parameter gradients (the generator phase's discriminator pass)
+    K.bn_bwd_apply_stats(dy, xt, part, ntb, rows, gt, mean, invstd, None, None, dy)
+    assert torch.equal(dy, outs["folded"])
 
 
 FINISH_BN_CASES = [  # name, mode, N, cin parts, H, W (input), Co

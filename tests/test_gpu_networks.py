@@ -886,6 +886,46 @@ def test_eval_caches_follow_parameter_and_buffer_writes(precision):
         assert torch.equal(G(x), y3)
 
 
+@pytest.mark.parametrize("n_layers", [1, 2, 3])
+def test_discriminator_gradient_ranges_tile_the_arena(n_layers):
+    """Data parallel: the discriminator's gradients cross the ranks as [grad_bucket, total) and [0, grad_bucket) - together
+    exactly the arena, whatever the depth (models.py:214 n_layers), and the early range holds the two innermost convolutions."""
+    D = pfa_gan.NLayerDiscriminator(6, ndf=8, n_layers=n_layers).cuda()
+    eng = D.engine(torch.bfloat16, in_split=(3, 3))
+    lo, level = eng.grad_bucket()
+    total = eng.flat.total
+    assert 0 < lo < total and level == len(eng.layers) - 2
+    inner = [eng.flat.slots[id(L.w)] for L in eng.layers[-2:]]
+    assert all(lo <= o and o + n <= total for o, n in inner)
+    assert all(o + n <= lo for o, n in (eng.flat.slots[id(L.w)] for L in eng.layers[:-2]))
+    assert lo % 4 == 0                                # 16-byte aligned: a range Adam and the collective can take
+
+
+def test_eager_contexts_free_replaced_buffers_and_pinned_ones_shelve_them():
+    """engine.Ctx: an eager context (eval forwards on tiles of changing size: generate_uint8's scratch context) hands a
+    replaced buffer back to the allocator - memory stays bounded however often two shapes alternate; a pinned context (a
+    hipGraph / launch list holds its addresses, or side streams use it) keeps one buffer per shape and takes it up again."""
+    torch.manual_seed(0)
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda().eval()
+    xs = [torch.rand((2, 3, 64, 64), device="cuda") * 2 - 1, torch.rand((1, 3, 96, 32), device="cuda") * 2 - 1]
+    ref = [G.generate_uint8(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for i in range(12):
+        out = G.generate_uint8(xs[i % 2])
+        assert torch.equal(out, ref[i % 2])
+    torch.cuda.synchronize()
+    del out
+    assert torch.cuda.memory_allocated() <= base + (1 << 20), "an eager context must not accumulate replaced buffers"
+    ctx = G.engine().new_ctx()
+    ctx.pin()
+    a = ctx.buf("t", (4, 8), torch.float32)
+    b = ctx.buf("t", (2, 8), torch.float32)
+    assert ctx.buf("t", (4, 8), torch.float32).data_ptr() == a.data_ptr()      # the shelved buffer of that shape
+    assert ctx.buf("t", (2, 8), torch.float32).data_ptr() == b.data_ptr()
+    assert len(ctx._shelf) == 1
+
+
 def test_launch_list_records_calls_events_and_replays():
     """pfa_replay: library calls on two streams with an event between them, recorded once (they also run), re-issued by one
     C call; a struct argument is deep-copied; a failing op reports its index."""

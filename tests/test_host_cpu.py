@@ -257,3 +257,109 @@ def test_siamese_unet_dropin_matches_reference_golden(golden):
     np.testing.assert_allclose(net.dconv_down1[0].weight.grad.numpy(), z["siamese.grad_down1"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(net.state_dict()["bottleneck.1.running_mean"].numpy(), z["siamese.rm_after_train"],
                                rtol=1e-5, atol=1e-6)
+
+
+def test_dataset_contract_pixel_values_labels_and_layout(tmp_path):
+    """The batch-dict contract the step consumes (reference dataset.py:13-36 collate + JointToTensor, :136-159 resize +
+    normalise, :229-237 bad samples, :248-270 directory layouts), pinned on hand-written PNGs:
+    image = x/255*2-1 exactly, label = (L > 128) as int64, synthetic samples are named <city>_synth, a sample whose file
+    goes bad after the scan comes back as None and is dropped by collate_fn_skip_none."""
+    from PIL import Image
+    from pfa_gan import data as D
+
+    h, w = 4, 6
+    rng = np.random.RandomState(5)
+    px1 = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    px1[0, 0], px1[0, 1], px1[0, 2] = (0, 0, 0), (255, 255, 255), (128, 127, 129)
+    px2 = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    lab = np.array([[0, 127, 128, 129, 255, 200]] * h, dtype=np.uint8)          # the threshold is strict: 128 -> 0, 129 -> 1
+    images, labels = tmp_path / "images", tmp_path / "labels"
+
+    def real_city(name, a=px1, b=px2, m=lab):
+        (images / name / "pair").mkdir(parents=True)
+        (labels / name / "cm").mkdir(parents=True)
+        Image.fromarray(a).save(images / name / "pair" / "img1.png")
+        Image.fromarray(b).save(images / name / "pair" / "img2.png")
+        Image.fromarray(m, mode="L").save(labels / name / "cm" / "cm.png")
+
+    real_city("paris")
+    real_city("pisa")
+    (images / "nolabel" / "pair").mkdir(parents=True)                            # label missing: skipped at the scan
+    Image.fromarray(px1).save(images / "nolabel" / "pair" / "img1.png")
+    Image.fromarray(px2).save(images / "nolabel" / "pair" / "img2.png")
+    (images / "broken" / "pair").mkdir(parents=True)                            # unreadable image: skipped at the scan
+    (labels / "broken" / "cm").mkdir(parents=True)
+    (images / "broken" / "pair" / "img1.png").write_bytes(b"not a png")
+    Image.fromarray(px2).save(images / "broken" / "pair" / "img2.png")
+    Image.fromarray(lab, mode="L").save(labels / "broken" / "cm" / "cm.png")
+    (images / "stray.txt").write_text("not a city directory")
+
+    samples = D.scan_dataset(str(images), str(labels))
+    assert [s["city"] for s in samples] == ["paris", "pisa"]
+    assert samples[0]["img1"].endswith(os.path.join("paris", "pair", "img1.png"))
+    assert samples[0]["label"].endswith(os.path.join("paris", "cm", "cm.png"))
+
+    # no resize: exact values
+    ds = D.BaseChangeDetectionDataset(samples, target_size=(h, w), augment=False)
+    item = ds[0]
+    want1 = torch.from_numpy(px1).permute(2, 0, 1).float().div(255) * 2.0 - 1.0      # TF.to_tensor, then JointNormalize
+    want2 = torch.from_numpy(px2).permute(2, 0, 1).float().div(255) * 2.0 - 1.0
+    assert item["image1"].dtype == torch.float32 and item["image1"].shape == (3, h, w)
+    assert torch.equal(item["image1"], want1) and torch.equal(item["image2"], want2)
+    assert float(item["image1"][0, 0, 0]) == -1.0 and float(item["image1"][0, 0, 1]) == 1.0
+    assert item["label"].dtype == torch.int64 and item["label"].shape == (h, w)
+    assert item["label"][0].tolist() == [0, 0, 0, 1, 1, 1]
+    assert item["city"] == "paris"
+
+    # resize path (train_gan.py:32,108 resizes everything to TARGET_SIZE): shape, dtype, range; labels stay {0, 1} (nearest)
+    big = D.BaseChangeDetectionDataset(samples, target_size=(8, 8), augment=False)[1]
+    assert big["image1"].shape == (3, 8, 8) and big["image1"].dtype == torch.float32
+    assert float(big["image1"].min()) >= -1.0 and float(big["image1"].max()) <= 1.0
+    assert big["label"].shape == (8, 8) and big["label"].dtype == torch.int64
+    assert set(big["label"].unique().tolist()) <= {0, 1} and int(big["label"].sum()) > 0
+    flat = np.full((h, w, 3), 77, dtype=np.uint8)                                # a constant image stays constant under bilinear
+    real_city("flat", a=flat, b=flat)
+    up = D.BaseChangeDetectionDataset(D.scan_dataset(str(images), str(labels)), target_size=(9, 5))
+    flat_item = [up[i] for i in range(len(up)) if up.samples[i]["city"] == "flat"][0]
+    assert torch.allclose(flat_item["image1"], torch.full((3, 9, 5), 77 / 255 * 2 - 1), atol=1e-6)
+
+    # collate: dict batches, None samples dropped, all-None -> None
+    batch = D.collate_fn_skip_none([ds[0], None, ds[1]])
+    assert batch["image1"].shape == (2, 3, h, w) and batch["label"].shape == (2, h, w) and batch["city"] == ["paris", "pisa"]
+    assert D.collate_fn_skip_none([None, None]) is None
+    os.remove(samples[1]["img2"])                                               # goes bad after the scan
+    assert ds[1] is None
+    assert D.collate_fn_skip_none([ds[0], ds[1]])["image1"].shape[0] == 1
+
+    # synthetic layout (what generate_synthetic_data.py:74-81 writes and dataset.py:248-266 scans)
+    simg, slab = tmp_path / "synthetic_data" / "images", tmp_path / "synthetic_data" / "labels"
+    (simg / "paris").mkdir(parents=True)
+    (slab / "paris").mkdir(parents=True)
+    for idx in (0, 3):
+        Image.fromarray(px1).save(simg / "paris" / f"img1_synth_{idx}.png")
+        Image.fromarray(px2).save(simg / "paris" / f"img2_synth_{idx}.png")
+        Image.fromarray(lab, mode="L").save(slab / "paris" / f"cm_synth_{idx}.png")
+    Image.fromarray(px1).save(simg / "paris" / "img1_synth_7.png")              # img2 missing: skipped
+    syn = D.scan_dataset(str(simg), str(slab), is_synthetic=True)
+    assert [s["city"] for s in syn] == ["paris_synth", "paris_synth"]
+    assert [os.path.basename(s["img2"]) for s in syn] == ["img2_synth_0.png", "img2_synth_3.png"]
+    assert [os.path.basename(s["label"]) for s in syn] == ["cm_synth_0.png", "cm_synth_3.png"]
+    got = D.BaseChangeDetectionDataset(syn, target_size=(h, w))[1]
+    assert torch.equal(got["image1"], want1) and got["city"] == "paris_synth"
+
+
+def test_launch_list_records_the_request_not_the_answer():
+    """_lib.Recorder copies by-reference argument blocks BEFORE the call: pfa_gather_gemm writes the planes it used and the
+    number of statistics tiles back into its argument struct, and a replay must pass the original request again."""
+    import ctypes
+    from pfa_gan import _lib
+    _lib.lib()
+    rec = _lib.Recorder()
+    a = _lib.GatherArgs()
+    a.struct_size, a.splitk, a.ntiles_stat = ctypes.sizeof(_lib.GatherArgs), 16, 0
+    st, keep = rec.snapshot("pfa_gather_gemm", (ctypes.byref(a), None))
+    a.splitk, a.ntiles_stat = 4, 99                       # what the entry point would write back
+    copy = [k for k in keep if isinstance(k, _lib.GatherArgs)][0]
+    assert (copy.splitk, copy.ntiles_stat) == (16, 0) and st.a0 == ctypes.addressof(copy)
+    rec.note_call("pfa_gather_gemm", 0, (st, keep))
+    assert len(rec.ops) == 1 and rec.ops[0].kind == _lib.OP_CALL and rec.ops[0].a == ctypes.addressof(st)
