@@ -39,7 +39,7 @@ FLOP_PER_TILE = {256: 12.046e9, 512: 48.18e9}      # generator-only forward
 # SURVEY.md 8(d) "algorithmic bytes per img-pair" (ideal fusion: every conv pass touches input, output and weights once, bf16
 # activations, fp32 weight gradients, Adam 28 B/parameter), at the batch per GPU it is quoted for
 BYTES_PER_PAIR = {(256, 16): 237.5e6, (512, 8): 747.3e6}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
 
 
 def parse():
@@ -294,6 +294,65 @@ def cpu_baseline_isolated(size, budget_s, infer=False):
                     sample=f"cpu_baseline child exceeded {3 * budget_s + 60:.0f} s")
 
 
+# ----------------------------------------------------------------------------------------------------- N > 1: what the collectives cost
+def comm_diagnostics(trainer, pool, args, world, barrier, ms_with):
+    """After the headline measurement, on every rank: (1) the same timed loop with the gradient all-reduces switched off
+    (GanTrainer.skip_collectives: the ranks' parameters diverge, which no longer matters) - the difference to the headline
+    ms/step is what the collectives cost the step, exposed or through contention; (2) each gradient range of the step
+    all-reduced alone, back to back: its time and bus bandwidth (2 (n-1)/n x bytes / time - above one xGMI link's ~153 GB/s
+    only a multi-link algorithm can be at work); (3) the bucket layout.  -> dict for config["comm"] (rank 0's view; times are
+    the max over ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    def tmax(x):
+        t = torch.tensor([x], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+    g_total, d_total = trainer.opt_g.flat().total, trainer.opt_d.flat().total
+    buckets, whens = trainer.G.grad_buckets()
+    d_lo = trainer.Dn.grad_bucket()[0]
+    esize = 2 if trainer.grad_payload else 4
+    ranges = [("G " + "/".join(str(x) for x in w), hi - lo) for (lo, hi), w in zip(buckets, whens)]
+    ranges += [("D(real) arena", d_total), ("D(fake) c4..c5", d_total - d_lo), ("D(fake) c1..c3", d_lo)]
+    probe = []
+    for name, n in ranges:
+        if n <= 0:
+            continue
+        buf = torch.zeros(n, dtype=torch.bfloat16 if trainer.grad_payload else torch.float32, device="cuda")
+        for _ in range(2):
+            dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ms = tmax(1e3 * (time.perf_counter() - t0) / reps)
+        probe.append(dict(range=name, mbytes=round(n * esize / 1e6, 2), ms=round(ms, 3),
+                          busbw_gbs=round(2 * (world - 1) / world * n * esize / (ms * 1e-3) / 1e9, 1)))
+        del buf
+    trainer.skip_collectives = True
+    try:
+        for i in range(3):
+            trainer.step_packed(*pool[i % len(pool)])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            trainer.step_packed(*pool[i % len(pool)])
+        barrier()
+        ms_without = tmax(1e3 * (time.perf_counter() - t0) / args.steps)
+    finally:
+        trainer.skip_collectives = False
+    return dict(ms_per_step_without_collectives=round(ms_without, 3), comm_cost_ms_per_step=round(ms_with - ms_without, 3),
+                payload="bf16" if trainer.grad_payload else "f32",
+                bytes_per_step_mb=round((g_total + 2 * d_total) * esize / 1e6, 1),
+                allreduce_alone=probe, backend=dist.get_backend(),
+                note="comm_cost = headline ms/step - the same loop without the gradient all-reduces; allreduce_alone: each "
+                     "gradient range of the step reduced by itself (5 back-to-back calls)")
+
+
 # ----------------------------------------------------------------------------------------------------- extra legs
 def fp32_leg(args, pool32_src, steps=5, warmup=2):
     """The parity mode (exact-f32 MFMA: the mode that meets the north star's 1e-3 / 1e-2 gate, and the reference's own
@@ -492,6 +551,7 @@ def main():
 
     # every rank takes part in the roofline pass: its steps carry the same gradient all-reduces as the timed ones
     roof = None if args.no_roofline else kernel_roofline(trainer, *pool[0], max(2, min(args.steps, 5)), args.precision)
+    comm = comm_diagnostics(trainer, pool, args, world, barrier, 1e3 * dt / args.steps) if world > 1 else None
     if rank == 0:
         pairs = world * args.batch * args.steps
         value = pairs / dt
@@ -526,6 +586,8 @@ def main():
                                        "so both the MFMA and the HBM fraction are reported"}
         if roof is not None:
             out["roofline"] = roof
+        if comm is not None:
+            out["config"]["comm"] = comm
         if world == 1 and not args.no_extras and args.precision == "bf16" and args.size == 256:
             # extra legs, AFTER the headline's timed region and roofline pass, each bounded to a fraction of a second of GPU
             # time: the parity mode on the same workload, and BASELINE config 5

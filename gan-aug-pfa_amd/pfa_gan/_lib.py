@@ -177,13 +177,32 @@ _RECORDER = None
 class LaunchList:
     """A recorded sequence of library calls, event records and stream waits; replay() re-issues it with one C call."""
 
-    def __init__(self, ops, keep):
+    def __init__(self, ops, keep, patch=()):
         self.n = len(ops)
         self.ops = (ReplayOp * max(self.n, 1))(*ops)
         self._keep = keep               # argument blocks, struct copies, events, streams: alive as long as the list
         self.calls = sum(1 for o in ops if o.kind == OP_CALL)
+        # pointer substitution: every pointer-typed field of the recorded argument blocks that held one of the `patch`
+        # addresses (the step's input tensors) when the list was recorded; replay(subst=) rewrites them, so ONE list serves
+        # any buffer of the same shape (no copy into static inputs in front of each replay)
+        self._sites = {int(p): [] for p in patch}
+        if self._sites:
+            for obj in keep:
+                if isinstance(obj, Structure):
+                    for field in obj._fields_:
+                        if field[1] is c_void_p and getattr(obj, field[0]) in self._sites:
+                            self._sites[getattr(obj, field[0])].append((obj, field[0]))
 
-    def replay(self):
+    def sites(self, ptr):
+        """Number of recorded pointer arguments that held `ptr` (a `patch` address of Recorder.finish)."""
+        return len(self._sites.get(int(ptr), ()))
+
+    def replay(self, subst=None):
+        """subst: {recorded address: address to use from now on} for addresses given to Recorder.finish(patch=...)."""
+        if subst:
+            for orig, new in subst.items():
+                for obj, name in self._sites[int(orig)]:
+                    setattr(obj, name, int(new))
         failed = c_int(-1)
         rc = _LIB.pfa_replay(ctypes.addressof(self.ops), self.n, ctypes.byref(failed))
         if rc != 0:
@@ -287,8 +306,9 @@ class Recorder:
         self.keep += [event, stream]
         self.ops.append(ReplayOp(OP_WAIT, 0, event.cuda_event, stream.cuda_stream))
 
-    def finish(self):
-        return LaunchList(self.ops, self.keep)
+    def finish(self, patch=()):
+        """patch: device addresses (the step's input tensors) that replay(subst=) may replace."""
+        return LaunchList(self.ops, self.keep, patch)
 
 
 def recorder():

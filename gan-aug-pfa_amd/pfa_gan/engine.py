@@ -537,20 +537,41 @@ class GeneratorEngine(_Engine):
         return fake
 
     def grad_buckets(self):
-        """Contiguous ranges of the gradient arena in the order the backward completes them:
-        [decoder d7..d1] (final when the decoder loop ends), [e_{D-2}..e_D] (final after the three innermost
-        encoder levels), [e3..e_{D-3}] (after level e3), [e1, e2] (end of backward: a small last bucket keeps the update
-        that nothing can hide short).  Arena order is module.parameters() order: e1, e2, bn2, ..., eD, dD, bnD, ..., d2,
-        bn2, d1 - so each bucket is one slice.  -> (buckets, encoder levels (0-based) after which buckets 1.. are final; the
-        last bucket is final at the end)."""
+        """Contiguous ranges of the gradient arena in the order the backward completes them, with the point of the backward
+        at which each is final: -> (buckets, whens); whens[i] = ("dec", k): after decoder level k (0-based, outermost = 0),
+        ("enc", k): after encoder level k, ("end",): when the backward ends.
+          [d4..d1]            final after decoder level 3: the outer decoder levels run first (22 MB that can cross the ranks -
+                              and be updated - under the whole inner decoder and encoder backward)
+          [dD..d5]            final when the decoder loop ends (84 MB)
+          [e_{D-2}..e_D]      after the three innermost encoder levels (50 MB)
+          [e3..e_{D-3}]       after level e3
+          [e1, e2]            end of backward: a small last bucket keeps the update that nothing can hide short
+        Arena order is module.parameters() order: e1, e2, bn2, ..., eD, dD, bnD, ..., d2, bn2, d1 - so each bucket is one
+        slice.  Shallow generators merge what they do not have."""
         off = lambda L: self.flat.slots[id(L.w)][0]
-        x_dec = off(self.up[self.D - 1])
-        mid = max(self.D - 3, 1)
+        D = self.D
+        x_dec = off(self.up[D - 1])
+        buckets, whens = [], []
+        split = 3 if D - 1 > 3 else None          # d4's weight is the first parameter of the outer-decoder range
+        if split is not None:
+            x_out = off(self.up[split])
+            buckets += [(x_out, self.flat.total), (x_dec, x_out)]
+            whens += [("dec", split), ("dec", D - 1)]
+        else:
+            buckets.append((x_dec, self.flat.total))
+            whens.append(("dec", D - 1))
+        mid = max(D - 3, 1)
         x_mid = off(self.down[mid])
+        buckets.append((x_mid, x_dec))
+        whens.append(("enc", mid))
         if mid > 2:
             x_low = off(self.down[2])
-            return [(x_dec, self.flat.total), (x_mid, x_dec), (x_low, x_mid), (0, x_low)], [mid, 2]
-        return [(x_dec, self.flat.total), (x_mid, x_dec), (0, x_mid)], [mid]
+            buckets += [(x_low, x_mid), (0, x_low)]
+            whens += [("enc", 2), ("end",)]
+        else:
+            buckets.append((0, x_mid))
+            whens.append(("end",))
+        return buckets, whens
 
     def backward(self, ctx, dpre, garena, side=None, bucket_ready=None):
         """dpre: gradient w.r.t. the pre-Tanh output, NHWC.  Accumulates every parameter gradient into garena.
@@ -565,6 +586,13 @@ class GeneratorEngine(_Engine):
         B, H, W, _ = v["x"].shape
         g_skip, g_up = {}, {}
         ready = {}          # node tag -> conv-output gradient already produced by a fused dgrad epilogue
+        whens = self.grad_buckets()[1]
+
+        def dec_hook(k):
+            # every kernel that writes the gradients of decoder levels 0..k or reads their weights has been issued
+            if bucket_ready is not None and ("dec", k) in whens and k < D - 1:
+                self._join_sides(side)
+                bucket_ready(whens.index(("dec", k)))
         # ---- decoder, outermost first
         d = dpre
         for k in range(D):
@@ -606,10 +634,13 @@ class GeneratorEngine(_Engine):
             else:
                 g_up[k + 1] = ctx.buf(f"g.up{k + 1}", srcs[1].shape, dt)
                 K.gather_gemm(K.CONV_S2, [d], L.w_bwd, L.conv.in_channels, [g_skip[k], g_up[k + 1]], (B, h, w), self.ws)
-        levels = self.grad_buckets()[1]
-        self._join_sides(side)
+            dec_hook(k)
+        # (the last decoder bucket: final here)
         if bucket_ready is not None:
-            bucket_ready(0)
+            self._join_sides(side)
+            bucket_ready(whens.index(("dec", D - 1)))
+        else:
+            self._join_sides(side)
         # ---- encoder, innermost first
         g_down = None
         for k in range(D - 1, -1, -1):
@@ -644,12 +675,12 @@ class GeneratorEngine(_Engine):
                     g_down = ctx.buf(f"g.down{k - 1}", src.shape, dt)
                     K.gather_gemm(K.TCONV_S2, [dr], L.w_bwd, src.shape[3], [g_down], (B, h, w), self.ws)
             # (after this level's input gradient, the last reader of its weights: the caller may update the bucket now)
-            if bucket_ready is not None and k in levels and k > 0:
+            if bucket_ready is not None and ("enc", k) in whens and k > 0:
                 self._join_sides(side)
-                bucket_ready(1 + levels.index(k))
+                bucket_ready(whens.index(("enc", k)))
         self._join_sides(side)
         if bucket_ready is not None:
-            bucket_ready(len(levels) + 1)
+            bucket_ready(whens.index(("end",)))
 
 
 # ------------------------------------------------------------------------------------ discriminator

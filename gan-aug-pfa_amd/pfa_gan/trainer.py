@@ -184,6 +184,7 @@ class GanTrainer:
         self._payload = {}
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self._g_reduced = False
+        self.skip_collectives = False        # bench.py's comm-off timing pass (never set in training)
         dev = self.G.device
         self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
         if overlap or use_graph:
@@ -406,6 +407,11 @@ class GanTrainer:
         """Sum-all-reduce of a float32 gradient range over the ranks on the current stream; returns a handle with .wait()
         (the current stream waits, not the host) when async_op.  With grad_payload == "bf16" the range travels as bfloat16
         through a persistent staging buffer per call site (`key`)."""
+        if self.skip_collectives:            # measurement only (bench.py: what the collectives cost the step): ranks diverge
+            class _Done:
+                def wait(self_inner):
+                    pass
+            return _Done() if async_op else None
         if self.grad_payload is None:
             return torch.distributed.all_reduce(t, group=self.pg, async_op=async_op)
         buf = self._payload.get(key)
@@ -517,17 +523,29 @@ class GanTrainer:
         if self.use_graph == "replay" and torch.cuda.current_stream().cuda_stream != self._capture_stream:
             raise PfaError("GanTrainer(use_graph='replay'): the launch lists were recorded on another current stream")
         sa, sb = self._static
-        sa.copy_(xa)
-        sb.copy_(xb)
+        subst = None
+        if self.use_graph == "replay" and xa.is_contiguous() and xb.is_contiguous():
+            # a launch list takes the batch's own buffers: the recorded input addresses are rewritten, nothing is copied
+            subst = {sa.data_ptr(): xa.data_ptr(), sb.data_ptr(): xb.data_ptr()}
+        else:
+            sa.copy_(xa)
+            sb.copy_(xb)
         for o in (self.opt_g, self.opt_d):        # an eager step since the last replay moved only the host count
             o.sync_step_dev()
         if ready is not None:                     # the side stream's D(real) waits for this, not for the previous step's tail
             ready.record(torch.cuda.current_stream())
-        self._graphs[0].replay()
-        self._allreduce(self.opt_d)
-        self._graphs[1].replay()
-        self._allreduce(self.opt_g)
-        self._graphs[2].replay()
+        if subst is not None:
+            self._graphs[0].replay(subst)
+            self._allreduce(self.opt_d)
+            self._graphs[1].replay(subst)
+            self._allreduce(self.opt_g)
+            self._graphs[2].replay(subst)
+        else:
+            self._graphs[0].replay()
+            self._allreduce(self.opt_d)
+            self._graphs[1].replay()
+            self._allreduce(self.opt_g)
+            self._graphs[2].replay()
         for o in (self.opt_g, self.opt_d):        # each replay ticks the device counter once
             o.steps += 1
             o._dev_steps += 1
@@ -545,7 +563,7 @@ class GanTrainer:
         if self.use_graph == "replay":
             with _lib.Recorder() as rec:
                 fn()
-            return rec.finish()
+            return rec.finish(patch=[t.data_ptr() for t in self._static])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             fn()

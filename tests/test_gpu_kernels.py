@@ -1070,7 +1070,7 @@ def test_batchnorm_roundtrip(dtype, ws):
 STATS_FUSED_CASES = [  # name, N, C, H, W, partial rows
     ("c16_3tiles", 3, 16, 9, 7, 3),           # fewer channels than a group: one group of 16
     ("c64_17tiles", 2, 64, 12, 10, 17),       # one full group, more partial rows than virtual lanes
-    ("c192_130tiles", 2, 192, 24, 23, 130),   # three groups, two load rounds per lane, ragged row blocks
+    ("c256_130tiles", 2, 256, 24, 23, 130),   # four groups, two load rounds per lane, ragged row blocks
     ("c128_256tiles", 1, 128, 40, 36, 256),   # the limit of the folded form
 ]
 

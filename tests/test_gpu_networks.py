@@ -421,6 +421,16 @@ def test_bench_two_ranks_contract(spelling):
     rf = out["roofline"]
     assert rf["avg_launch_us"] > 0 and rf["flop_per_launch"] > 0 and rf["achieved"] >= 0 and "cpu_baseline" not in out
     assert any(k["kernel"].startswith("k_wgrad") for k in out["roofline"]["kernels"])
+    # N > 1 diagnostics: what the collectives cost the step, every gradient range reduced alone, the bucket layout
+    comm = out["config"]["comm"]
+    assert comm["ms_per_step_without_collectives"] > 0 and comm["payload"] == "f32" and comm["backend"] == "gloo"
+    assert abs(comm["comm_cost_ms_per_step"] - (out["ms_per_step"] - comm["ms_per_step_without_collectives"])) < 2e-3
+    names = [p["range"] for p in comm["allreduce_alone"]]
+    assert sum(n.startswith("G ") for n in names) >= 3 and "D(real) arena" in names
+    assert all(p["ms"] > 0 and p["busbw_gbs"] > 0 and p["mbytes"] > 0 for p in comm["allreduce_alone"])
+    g_mb = sum(p["mbytes"] for p in comm["allreduce_alone"] if p["range"].startswith("G "))
+    d_mb = [p["mbytes"] for p in comm["allreduce_alone"] if p["range"] == "D(real) arena"][0]
+    assert abs(g_mb + 2 * d_mb - comm["bytes_per_step_mb"]) < 0.1            # the generator's buckets tile its arena
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -958,6 +968,40 @@ def test_launch_list_records_calls_events_and_replays():
     bad = _lib.LaunchList([_lib.ReplayOp(_lib.OP_CALL, 9999, 1, None)], [])
     with pytest.raises(_lib.PfaError, match="op 0"):
         bad.replay()
+
+
+def test_launch_lists_take_the_batches_own_buffers():
+    """GanTrainer(use_graph="replay"): one recorded launch list serves every batch of the recorded shape - the input
+    addresses in its argument blocks are rewritten per step (LaunchList.replay(subst=)), nothing is copied into static
+    buffers - and computes exactly what the eager three-stream step does on the same sequence of batches."""
+    def run(mode):
+        torch.manual_seed(3)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda()
+        tr = pfa_gan.GanTrainer(G, D, precision="bf16", inputs_resident=True, use_graph=mode)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        pool = []
+        for _ in range(3):
+            a = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+            b = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+            pool.append((tr.pack(a), tr.pack(b)))
+        torch.cuda.synchronize()
+        out = [tr.step_packed(*pool[i % 3]).clone() for i in range(7)]
+        torch.cuda.synchronize()
+        return tr, pool, torch.stack(out), tr.opt_g.flat().data.clone(), tr.opt_d.flat().data.clone()
+    tr, pool, l_list, pg_list, pd_list = run("replay")
+    _, _, l_eager, pg_eager, pd_eager = run(False)
+    assert torch.equal(l_list, l_eager) and torch.equal(pg_list, pg_eager) and torch.equal(pd_list, pd_eager)
+    assert len({p[0].data_ptr() for p in pool}) == 3                       # three distinct input buffers were stepped on
+    sa, sb = tr._static
+    assert tr._graphs[0].sites(sa.data_ptr()) >= 3 and tr._graphs[0].sites(sb.data_ptr()) >= 1     # D(real), D(fake), G read A
+    assert tr._graphs[1].sites(sa.data_ptr()) >= 1 and tr._graphs[1].sites(sb.data_ptr()) >= 1     # G-phase D pass; the L1 term
+    # the static buffers were only ever read by the recording run: a replay that still used them would have trained on
+    # batch 0 seven times - different losses from the eager run's (checked above) - and poisoning them changes nothing now
+    sa.fill_(float("nan")); sb.fill_(float("nan"))
+    l8 = tr.step_packed(*pool[1]).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(l8).all()
 
 
 def test_step_marks_follow_the_phases_of_the_step():

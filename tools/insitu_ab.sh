@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 for arm in base alt; do
   rm -rf $O/$arm
   if [ $arm = alt ]; then export PFA_KNOBS=$KN; else unset PFA_KNOBS; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$arm -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline > $O/$arm.json 2> $O/$arm.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$arm -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline --no-extras > $O/$arm.json 2> $O/$arm.err
   cp $O/$arm/*/*_kernel_stats.csv $O/${arm}_kernel_stats.csv
   rm -rf $O/$arm
 done

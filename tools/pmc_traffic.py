@@ -89,7 +89,7 @@ if __name__ == "__main__":
                note="bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request); averages "
                     "over every launch of the kernel in 4 single-stream steps",
                command="rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --steps 3 --warmup 1 --repeats 1 "
-                       "--no-overlap --no-cpu-baseline --no-roofline")
+                       "--no-overlap --no-cpu-baseline --no-roofline --no-extras")
     out.setdefault("workloads", {})[key] = kernels
     json.dump(out, open(out_path, "w"), indent=1)
     for k, v in kernels.items():

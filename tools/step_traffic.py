@@ -1,6 +1,6 @@
 """Per-launch fabric/HBM traffic (L2 misses) vs duration of the MFMA kernels inside one training step.
 usage: step_traffic.py <dir of a `rocprofv3 --kernel-trace --pmc FETCH_SIZE` run> <dir of a `--pmc WRITE_SIZE` run>
-(both of `python bench.py --steps 3 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline`).
+(both of `python bench.py --steps 3 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline --no-extras`).
 bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 corrections, MI355X_MICROARCH.md)."""
 import collections, csv, glob, sys
 
