@@ -655,7 +655,7 @@ bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int sp
     // three-stream step that is faster (round 2: 3.306 vs 3.329 ms; round 3, three same-box pairs: 3.044 vs 3.065 ms), because
     // the other streams use the idle half of the chip; alone on the GPU the launch takes 113 us instead of 60 + 12, which is
     // what a one-stream kernel trace shows.  The timed step decides: 128; 192 restores the K-sliced plan.)
-    if (n % 128 == 0 && (long long)tiles * (n / 128) >= (pfa_knob(10) > 0 ? pfa_knob(10) : 128)) b = 128;
+    if (n % 128 == 0 && (long long)tiles * (n / 128) >= (pfa_knob(10) > 0 ? pfa_knob(10) : (pfa_knob(15) ? 192 : 128))) b = 128;     // knob 15: the launch is alone on the GPU
     else if ((long long)tiles * (n / 64) >= 192 && pfa_knob(3) == 7) b = 64;          // knob 3 = 7 only: measured slower (below)
     else if (n % 128 == 0) {
         b = 128;

@@ -389,7 +389,9 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
     const int nss = (k.ctot / 64) * (k.mode == PFA_CONV_S2 ? 4 : 1);
     // (in-situ sweep of the threshold: 192 -> 3.41 ms per step, 128 -> 3.37, 256 -> 3.47, 320 -> 3.65: a launch that leaves CUs
     // idle is not lost inside the three-stream step, narrower tiles are)
-    const int want = pfa_knob(6) > 0 ? pfa_knob(6) : 128;
+    // (knob 15, set by the engines around passes that run alone on the GPU - the generator phase's discriminator pass: no other
+    // stream fills the CUs a 128-workgroup launch leaves idle there, so such a launch narrows its channel tile)
+    const int want = pfa_knob(6) > 0 ? pfa_knob(6) : (pfa_knob(15) ? 192 : 128);
     pl.splitk = 1;
     if (k.n % 128 == 0 && tiles * (k.n / 128) >= want) pl.bn = 128;
     else if (tiles * (k.n / 64) >= want || k.splitk <= 1) pl.bn = 64;

@@ -73,6 +73,17 @@ def wait_stream(dst, src):
     wait_event(dst, ev)
 
 
+SOLO_HINT = __import__("os").environ.get("PFA_SOLO_HINT", "1") != "0"      # A/B switch
+
+
+def set_solo(flag):
+    """Tell the library that the launches that follow run alone on the GPU (no other stream of the step has work): launch
+    plans then fill the chip instead of leaving CUs to the other streams.  A library call like any other: launch lists
+    record and replay it in order."""
+    if SOLO_HINT:
+        check(lib().pfa_set_knob(15, 1 if flag else 0), "pfa_set_knob")
+
+
 def axpy(y, x, alpha=1.0):
     """y += alpha * x (float32, same length) on the current stream."""
     check(lib().pfa_axpy(ptr(y), ptr(x), y.numel(), float(alpha), stream()), "pfa_axpy")

@@ -230,6 +230,7 @@ class GanTrainer:
         G, Dn = self.G, self.Dn
         parts = self._parts
         garena = self.opt_d.flat().grad
+        K.set_solo(self.side is None)         # one stream: every launch is alone on the GPU (see kernels.set_solo)
         if self.side is None:
             garena2 = self.opt_d.grad2()      # an arena per pass, as on three streams: a second pass ADDING to the first
             self.opt_d.zero_grad()            # one's sums would depend on the order of its float atomics
@@ -322,10 +323,16 @@ class GanTrainer:
         self._mark("Adam(D) done")
         self.opt_g.zero_grad()
         fake = self.gctx.v["fake"]
-        lg = Dn.forward([xa, fake], self.ctx_r, train=True)
-        dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
-        self._nparts[2] = K.bce_logits_parts(lg, 1.0, 1.0, 1.0, self._parts[128:192], dl_g)
-        dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
+        # (this pass runs alone on the GPU - the generator's backward waits for its result, nothing else is ready - so its
+        # launches plan for the whole chip)
+        K.set_solo(True)
+        try:
+            lg = Dn.forward([xa, fake], self.ctx_r, train=True)
+            dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
+            self._nparts[2] = K.bce_logits_parts(lg, 1.0, 1.0, 1.0, self._parts[128:192], dl_g)
+            dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
+        finally:
+            K.set_solo(self.side is None)
         if self._ev_d_free is not None and (not graph_safe or self._listing):
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True

@@ -75,7 +75,9 @@ uint64_t pfa_launch_count(void);
  * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256);
  * id 13: two tap rows per workgroup in the patch weight gradient (wgrad_patch.hip): 2 = always, 3 = where its ring keeps
  * four stages (stride 1, 4x16 tile); id 14: partial rows up to which the BatchNorm coefficient launch is folded into the pass
- * that applies it (pfa_bn_act_stats / pfa_bn_bwd_apply_stats; 0 = 256, -1 = never). */
+ * that applies it (pfa_bn_act_stats / pfa_bn_bwd_apply_stats; 0 = 256, -1 = never); id 15: 1 = the launches that follow run
+ * alone on the GPU (set and cleared by the engines around such passes, recorded in launch lists): plans that leave CUs to
+ * other streams - the un-sliced stride-1 input gradient, 128-channel patch tiles on 128 workgroups - fill the chip instead. */
 int pfa_set_knob(int id, int value);
 /* Developer timing: device memory (caller-owned; NULL = off) into which the stride-2 patch kernels write clock stamps per
  * workgroup: conv (uint64[workgroups][16]: 8 shader-clock stamps - entry, first fragments, K loop done, accumulators in LDS,

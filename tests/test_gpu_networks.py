@@ -280,6 +280,63 @@ def test_bf16_mode_tracks_fp32(golden):
             assert int(v) == int(zs[f"step.{sname}.g.{k}"])
 
 
+@pytest.mark.parametrize("case", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_bf16_step_matches_the_bf16_storage_step_oracle(case):
+    """The throughput mode's WHOLE STEP, gated tightly: GanTrainer(precision="bf16") against oracle/bf16.py - forward,
+    backward and Adam with a bf16 rounding at the engines' storage points (anchored to the pinned float32 oracle by
+    tests/test_oracle_golden.py).  What is left between the two is the order of float32 sums, rounding ties and the
+    activation knife-edges a tie can flip: losses <= 1e-3 relative, every conv weight gradient <= 1e-2 in relative L2, the
+    BatchNorm buffers and counters, and Adam - whose first step moves a parameter by +-lr whatever the gradient's size, so
+    one flipped sign is a whole step - moving >= 99 % of the parameters alike (train_gan.py:52-71)."""
+    from oracle import bf16 as o16
+    name, nd, ngf, ndf, n, h, steps = case
+    gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False)
+    a = fill.uniform(f"bf16step.{name}.a", (n, 3, h, h))
+    b = fill.uniform(f"bf16step.{name}.b", (n, 3, h, h))
+    G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+    D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+    load(G, gst)
+    load(D, dst)
+    tr = pfa_gan.GanTrainer(G, D, precision="bf16")
+    losses = tr.step(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+    og, od = {k: v.copy() for k, v in gst.items()}, {k: v.copy() for k, v in dst.items()}
+    ld, lg, ex = o16.gan_step(og, od, ostep.new_adam_state(og), ostep.new_adam_state(od), a, b, nd, 3)
+    assert abs(losses[0] - ld) <= 1e-3 * abs(ld), (losses, ld)
+    assert abs(losses[1] - lg) <= 1e-3 * abs(lg), (losses, lg)
+    fake = pfa_gan.kernels.unpack_nchw(tr.gctx.v["fake"], 3).cpu().numpy()
+    dfake = np.abs(fake - ex["fake_b"])
+    assert np.mean(dfake > 0) < 0.05 and dfake.max() <= 2.0 ** -6, (np.mean(dfake > 0), dfake.max())
+    # raw gradients: the generator's arena; the discriminator's two arenas (real | fake pass) summed
+    torch.cuda.synchronize()
+    for k, p in G.named_parameters():
+        want = ex["g_grads"][k]
+        got = p.grad.cpu().numpy()
+        if want.ndim == 4:
+            rel = np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
+            assert rel <= 1e-2, f"G grad {k}: rel L2 {rel:.2e}"
+    flat_d, g2 = tr.opt_d.flat(), tr.opt_d.grad2()
+    for k, p in D.named_parameters():
+        want = ex["d_grads"][k]
+        o, cnt = flat_d.slots[id(p)]
+        got = (p.grad + flat_d._view(g2, p, o, cnt)).cpu().numpy()
+        if want.ndim == 4:
+            rel = np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
+            assert rel <= 1e-2, f"D grad {k}: rel L2 {rel:.2e}"
+    for mod, ref in ((G, og), (D, od)):
+        alike = total = 0
+        for k, v in mod.state_dict().items():
+            got = v.cpu().numpy()
+            if k.endswith("num_batches_tracked"):
+                assert int(got) == int(ref[k]), k
+            elif ostep.is_param(k):
+                alike += int(np.sum(np.abs(got - ref[k]) < 0.5 * ostep.LR))
+                total += ref[k].size
+            else:
+                assert_close(got, ref[k], 1e-4, 2e-3, f"buffer {k}")
+        assert alike >= 0.99 * total, f"only {alike / total:.2%} of the parameters moved as in the bf16 step oracle"
+
+
 def test_gpu_input_without_library_path_is_an_error(monkeypatch):
     """No silent fallback: if the .so cannot be found the GPU path raises."""
     monkeypatch.setattr(_lib, "_LIB", None)

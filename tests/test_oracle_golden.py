@@ -220,3 +220,40 @@ def test_bf16_storage_oracle_tracks_the_pinned_fp32_oracle():
     d16 = nets.discriminator_fwd_bf16(dst, xd)
     d32, _, _ = nets.discriminator_fwd(dst, xd)
     assert np.abs(d16 - d32).max() < 3e-2 * max(1.0, np.abs(d32).max())
+
+
+def test_bf16_step_oracle_tracks_the_pinned_fp32_oracle():
+    """oracle/bf16.py - the checker of the throughput mode's whole-step gate (forward, backward and Adam with a bf16 rounding
+    at the engines' storage points) - is the pinned float32 step (oracle/step.py, held to the reference's goldens above)
+    plus roundings: losses within 2 %, every weight gradient within bf16's drift in the L2 sense, the same BatchNorm
+    counters, and Adam moving (almost) every parameter the same way."""
+    from oracle import bf16 as o16, step as ostep
+    nd, ngf, ndf, n, h = 5, 8, 8, 2, 32
+    a = fill.uniform("bf16step.a", (n, 3, h, h))
+    b = fill.uniform("bf16step.b", (n, 3, h, h))
+    g0 = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False)
+    d0 = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False)
+    g32, d32 = {k: v.copy() for k, v in g0.items()}, {k: v.copy() for k, v in d0.items()}
+    g16, d16 = {k: v.copy() for k, v in g0.items()}, {k: v.copy() for k, v in d0.items()}
+    ld32, lg32, ex32 = ostep.gan_step(g32, d32, ostep.new_adam_state(g32), ostep.new_adam_state(d32), a, b, nd, 3)
+    ld16, lg16, ex16 = o16.gan_step(g16, d16, ostep.new_adam_state(g16), ostep.new_adam_state(d16), a, b, nd, 3)
+    assert abs(ld16 - ld32) <= 2e-2 * abs(ld32) and abs(lg16 - lg32) <= 2e-2 * abs(lg32)
+    assert np.array_equal(fill.bf16_round(ex16["fake_b"]), ex16["fake_b"])
+    assert np.abs(ex16["fake_b"] - ex32["fake_b"]).mean() < 1e-2
+    for name, g16s, g32s in (("G", ex16["g_grads"], ex32["g_grads"]), ("D", ex16["d_grads"], ex32["d_grads"])):
+        assert set(g16s) == set(g32s)
+        for k in g32s:
+            if g32s[k].ndim == 4:
+                rel = np.linalg.norm(g16s[k].astype(np.float64) - g32s[k]) / max(np.linalg.norm(g32s[k]), 1e-12)
+                assert rel < 0.15, f"{name} grad {k}: rel L2 {rel:.3f}"
+    for st16, st32 in ((g16, g32), (d16, d32)):
+        alike = total = 0
+        for k in st32:
+            if k.endswith("num_batches_tracked"):
+                assert int(st16[k]) == int(st32[k])
+            elif ostep.is_param(k):
+                alike += int(np.sum(np.abs(st16[k] - st32[k]) < 0.5 * ostep.LR))      # the first Adam step moves by +-lr
+                total += st32[k].size
+            else:
+                assert np.allclose(st16[k], st32[k], rtol=5e-2, atol=5e-3), k
+        assert alike > 0.9 * total, f"only {alike / total:.1%} of the parameters moved alike"
