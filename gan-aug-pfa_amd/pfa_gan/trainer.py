@@ -28,6 +28,8 @@ D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s
 DREAL_WGRAD_SIDE = _os.environ.get("PFA_DREAL_WGRAD_SIDE", "0") != "0"   # D(real)'s weight gradients on side2 instead of in line
 D_EARLY_REDUCE = _os.environ.get("PFA_D_EARLY_REDUCE", "1") != "0"     # data parallel: D's gradients reduced as they become final
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
+EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
+LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -271,6 +273,14 @@ class GanTrainer:
             K.wait_stream(self.side, main)
         self._mark("step", main)
         K.fill_zero(garena)
+        if EARLY_G_ZERO:
+            # the generator's gradient arena (167 MB) is zeroed here, on the second side stream under the generator's forward
+            # and D(real), instead of in front of the generator phase's discriminator pass, where the main stream runs alone:
+            # its readers (the previous step's bucketed Adam) are behind the main stream, its writers (this step's generator
+            # backward) behind the main stream's join with side2 after the D phase
+            K.wait_stream(self.side2, main)
+            with torch.cuda.stream(self.side2):
+                self.opt_g.zero_grad()
         with torch.cuda.stream(self.side):
             self._mark("side: D(real) begins")
             K.fill_zero(garena2)
@@ -321,7 +331,8 @@ class GanTrainer:
         self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=True)
         Dn.refresh_shadows(force=True)
         self._mark("Adam(D) done")
-        self.opt_g.zero_grad()
+        if self.side is None or not EARLY_G_ZERO:
+            self.opt_g.zero_grad()
         fake = self.gctx.v["fake"]
         # (this pass runs alone on the GPU - the generator's backward waits for its result, nothing else is ready - so its
         # launches plan for the whole chip)
@@ -360,6 +371,16 @@ class GanTrainer:
             def hook(i):
                 lo, hi = buckets[i]
                 if hi <= lo:
+                    return
+                if i == len(buckets) - 1 and LAST_BUCKET_MAIN:
+                    # the last bucket is final when the backward ends: the main stream has nothing left but to wait for
+                    # the side streams, so it takes this update itself - one cross-stream hand-off (~20 us each on the
+                    # critical path) instead of two (side -> side2 -> main)
+                    K.wait_stream(main, self.side)
+                    if self.pg is not None:
+                        self._reduce(garena[lo:hi], ("g", i), async_op=True).wait()
+                    self.opt_g.step_range(lo, hi, grad_scale=scale)
+                    G.refresh_shadows_range(lo, hi)
                     return
                 K.wait_stream(self.side2, main)
                 K.wait_stream(self.side2, self.side)
