@@ -263,5 +263,5 @@ def gan_step(g_st, d_st, g_opt, d_opt, real_a, real_b, num_downs=7, n_layers=3):
     dpre = r16((LAMBDA_L1 * np.sign(diff) / diff.size + dgan.astype(np.float64)) * (1.0 - fake.astype(np.float64) ** 2))
     g_grads = generator_bwd(g_st, gc, dpre, num_downs)
     _adam(g_st, g_grads, g_opt)
-    return loss_d, loss_g, dict(fake_b=fake, d_grads=d_grads, g_grads=g_grads, pred_real=pred_real, pred_fake=pred_fake,
-                                pred_g=pred_g)
+    return loss_d, loss_g, dict(fake_b=fake, d_grads=d_grads, d_grads_real=gr, d_grads_fake=gf, g_grads=g_grads,
+                                pred_real=pred_real, pred_fake=pred_fake, pred_g=pred_g)
