@@ -887,7 +887,7 @@ static dim3 stats_grid(int64_t rows, int c, int cg, int dtype, int ntiles) {
 }
 
 extern "C" int pfa_bn_stats_fused_supported(int dtype, int c, int ntiles) {
-    const int lim = pfa_knob(14) > 0 ? pfa_knob(14) : 256;
+    const int lim = pfa_knob(14) > 0 ? pfa_knob(14) : 512;      // (256 -> 512: +0.27 % on the step, three same-box pairs)
     return (dtype == PFA_BF16 || dtype == PFA_F32) && pfa_knob(14) >= 0 && ntiles > 0 && ntiles <= lim && stats_group(c, dtype) > 0;
 }
 

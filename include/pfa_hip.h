@@ -75,7 +75,7 @@ uint64_t pfa_launch_count(void);
  * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256);
  * id 13: two tap rows per workgroup in the patch weight gradient (wgrad_patch.hip): 2 = always, 3 = where its ring keeps
  * four stages (stride 1, 4x16 tile); id 14: partial rows up to which the BatchNorm coefficient launch is folded into the pass
- * that applies it (pfa_bn_act_stats / pfa_bn_bwd_apply_stats; 0 = 256, -1 = never); id 15: 1 = the launches that follow run
+ * that applies it (pfa_bn_act_stats / pfa_bn_bwd_apply_stats; 0 = 512, -1 = never); id 15: 1 = the launches that follow run
  * alone on the GPU (set and cleared by the engines around such passes, recorded in launch lists): plans that leave CUs to
  * other streams - the un-sliced stride-1 input gradient, 128-channel patch tiles on 128 workgroups - fill the chip instead. */
 int pfa_set_knob(int id, int value);
@@ -266,7 +266,7 @@ int pfa_bn_act(const void* raw, int64_t rows, int c, int dtype, const float* sca
  * its prologue (the same fixed order in every workgroup: the same bits, no hand-off between workgroups), normalises and
  * activates its rows; the workgroups of row block 0 write scale / shift / mean / invstd (read by the backward pass) and
  * update the running buffers `repeats` times.  Built for pfa_bn_stats_fused_supported(dtype, c, ntiles) != 0 (c a multiple
- * of 64, or a smaller power-of-two chunk count; at most 256 partial rows: pfa_set_knob(14, limit | -1 = never)); other
+ * of 64, or a smaller power-of-two chunk count; at most 512 partial rows: pfa_set_knob(14, limit | -1 = never)); other
  * shapes keep the two launches.  raw is [rows][c] (unpadded rows: BatchNorm layers have c % 16 bytes == 0). */
 int pfa_bn_stats_fused_supported(int dtype, int c, int ntiles);
 int pfa_bn_act_stats(const void* raw, int64_t rows, int c, int dtype, const float* psum, const float* psq, int ntiles,

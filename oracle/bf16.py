@@ -126,8 +126,11 @@ def generator_fwd(st, x, num_downs=7, bn_repeats=2):
     return fake, c, nb
 
 
-def generator_bwd(st, c, dpre, num_downs=7):
-    """dpre: stored (bf16) gradient w.r.t. the pre-Tanh output.  -> parameter gradients (float32) by state_dict key."""
+def generator_bwd(st, c, dpre, num_downs=7, unfused=False):
+    """dpre: stored (bf16) gradient w.r.t. the pre-Tanh output.  -> parameter gradients (float32) by state_dict key.
+    unfused: every input gradient is stored (bf16) before the activation backward of the node it belongs to - the engines'
+    route for launches whose epilogue does not carry the fused backward (kernels.fuse_ok)."""
+    rg = r16 if unfused else (lambda t: t)
     lv = c["lv"]
     w = lambda k: r16(st[k])
     grads = {}
@@ -142,11 +145,11 @@ def generator_bwd(st, c, dpre, num_downs=7):
             grads[lv[k]["up"] + ".bias"] = db
         cs = c["aR"][k].shape[1]
         if k == num_downs - 1:
-            dr_inner = r16(np.where(c["aR"][k] > 0, da, 0))                  # ReLU' from the stored activation's sign
+            dr_inner = r16(np.where(c["aR"][k] > 0, rg(da), 0))              # ReLU' from the stored activation's sign
             break
         g_skip[k] = r16(da[:, :cs])
         bn = c["bn_up"][k + 1]
-        d, dg, dbt = bn.backward(np.where(bn.y() > 0, da[:, cs:], 0).astype(F32))
+        d, dg, dbt = bn.backward(np.where(bn.y() > 0, rg(da[:, cs:]), 0).astype(F32))
         grads[lv[k + 1]["up_bn"] + ".weight"] = dg
         grads[lv[k + 1]["up_bn"] + ".bias"] = dbt
     dr = dr_inner
@@ -158,12 +161,14 @@ def generator_bwd(st, c, dpre, num_downs=7):
         bn = c["bn_down"][k - 1]
         if bn is not None:
             y = bn.y()
+            dx = rg(dx)
             dy = np.where(y > 0, dx, dx * F32(0.2)) + np.where(y > 0, g_skip[k - 1], 0)
             dr, dg, dbt = bn.backward(dy.astype(F32))
             grads[lv[k - 1]["down_bn"] + ".weight"] = dg
             grads[lv[k - 1]["down_bn"] + ".bias"] = dbt
         else:                                                                 # outermost level: sign from the stored aL
             aL = c["aL"][k - 1]
+            dx = rg(dx)
             dr = r16(np.where(aL > 0, dx, dx * F32(0.2)) + np.where(aL > 0, g_skip[k - 1], 0))
     return grads
 
@@ -192,8 +197,9 @@ def discriminator_fwd(st, x, n_layers=3):
     return h, c, nb
 
 
-def discriminator_bwd(st, c, dlogits, param_grads=True, need_dx=False):
-    """dlogits: stored (bf16).  -> (parameter gradients or {}, stored dx or None)"""
+def discriminator_bwd(st, c, dlogits, param_grads=True, need_dx=False, unfused=False):
+    """dlogits: stored (bf16).  -> (parameter gradients or {}, stored dx or None); unfused: see generator_bwd."""
+    rg = r16 if unfused else (lambda t: t)
     layers = c["layers"]
     grads = {}
     dr = dlogits
@@ -210,6 +216,7 @@ def discriminator_bwd(st, c, dlogits, param_grads=True, need_dx=False):
             dx_out = r16(dx) if need_dx else None
             break
         bn = c["bn"][i - 1]
+        dx = rg(dx)
         if bn is not None:
             dr, dg, dbt = bn.backward(np.where(bn.y() > 0, dx, dx * F32(0.2)).astype(F32))
             if param_grads:
@@ -236,8 +243,9 @@ def _adam(st, grads, opt):
         st[k], s["m"], s["v"] = ops.adam_step(st[k], g.astype(F32), s["m"], s["v"], s["t"], LR, BETAS[0], BETAS[1])
 
 
-def gan_step(g_st, d_st, g_opt, d_opt, real_a, real_b, num_downs=7, n_layers=3):
-    """One batch of train_gan_one_epoch with bf16 storage (see the module header); same contract as oracle.step.gan_step."""
+def gan_step(g_st, d_st, g_opt, d_opt, real_a, real_b, num_downs=7, n_layers=3, unfused=False):
+    """One batch of train_gan_one_epoch with bf16 storage (see the module header); same contract as oracle.step.gan_step.
+    unfused: the backward passes take the un-fused route at every node (generator_bwd)."""
     xa, xb = r16(real_a), r16(real_b)
     fake, gc, g_nb = generator_fwd(g_st, xa, num_downs, bn_repeats=2)
     pred_real, c_real, nb1 = discriminator_fwd(d_st, np.concatenate([xa, xb], 1), n_layers)
@@ -247,21 +255,21 @@ def gan_step(g_st, d_st, g_opt, d_opt, real_a, real_b, num_downs=7, n_layers=3):
     d_st.update(nb2)
     l_fake, dl_fake = _bce(pred_fake, 0.0, 0.5, 0.5)
     loss_d = F32(l_real + l_fake)
-    gr, _ = discriminator_bwd(d_st, c_real, dl_real)
-    gf, _ = discriminator_bwd(d_st, c_fake, dl_fake)
+    gr, _ = discriminator_bwd(d_st, c_real, dl_real, unfused=unfused)
+    gf, _ = discriminator_bwd(d_st, c_fake, dl_fake, unfused=unfused)
     d_grads = {k: (gr[k] + gf[k]).astype(F32) for k in gr}
     _adam(d_st, d_grads, d_opt)
     g_st.update(g_nb)
     pred_g, c_g, nb3 = discriminator_fwd(d_st, np.concatenate([xa, fake], 1), n_layers)
     d_st.update(nb3)
     l_gan, dl_gan = _bce(pred_g, 1.0, 1.0, 1.0)
-    _, d_in = discriminator_bwd(d_st, c_g, dl_gan, param_grads=False, need_dx=True)
+    _, d_in = discriminator_bwd(d_st, c_g, dl_gan, param_grads=False, need_dx=True, unfused=unfused)
     dgan = d_in[:, real_a.shape[1]:]
     diff = fake.astype(np.float64) - xb.astype(np.float64)
     l_l1 = LAMBDA_L1 * np.mean(np.abs(diff))
     loss_g = F32(l_gan + F32(l_l1))
     dpre = r16((LAMBDA_L1 * np.sign(diff) / diff.size + dgan.astype(np.float64)) * (1.0 - fake.astype(np.float64) ** 2))
-    g_grads = generator_bwd(g_st, gc, dpre, num_downs)
+    g_grads = generator_bwd(g_st, gc, dpre, num_downs, unfused=unfused)
     _adam(g_st, g_grads, g_opt)
     return loss_d, loss_g, dict(fake_b=fake, d_grads=d_grads, d_grads_real=gr, d_grads_fake=gf, g_grads=g_grads,
                                 pred_real=pred_real, pred_fake=pred_fake, pred_g=pred_g)

@@ -1071,7 +1071,7 @@ STATS_FUSED_CASES = [  # name, N, C, H, W, partial rows
     ("c16_3tiles", 3, 16, 9, 7, 3),           # fewer channels than a group: one group of 16
     ("c64_17tiles", 2, 64, 12, 10, 17),       # one full group, more partial rows than virtual lanes
     ("c256_130tiles", 2, 256, 24, 23, 130),   # four groups, two load rounds per lane, ragged row blocks
-    ("c128_256tiles", 1, 128, 40, 36, 256),   # the limit of the folded form
+    ("c128_512tiles", 1, 128, 40, 36, 512),   # the limit of the folded form
 ]
 
 
@@ -1089,7 +1089,7 @@ def test_batchnorm_statistics_folded_into_their_consumers(case, dtype, ws):
     y, cache, rm2, rv2, nbt2 = ops.bn_train_fwd(x, g, b, rm0, rv0, 5, repeats=2)
     xt = to_nhwc(x, dtype)
     rows = n * h * w
-    assert K.bn_stats_fused_ok(dtype, c, nt) and not K.bn_stats_fused_ok(dtype, c, 257) and not K.bn_stats_fused_ok(dtype, 96, nt)
+    assert K.bn_stats_fused_ok(dtype, c, nt) and not K.bn_stats_fused_ok(dtype, c, 513) and not K.bn_stats_fused_ok(dtype, 96, nt)
     xf = torch.from_numpy(x.transpose(0, 2, 3, 1).reshape(rows, c)).cuda().double()
     cuts = [round(i * rows / nt) for i in range(nt + 1)]          # nt row tiles of uneven length (some may be empty)
     zero = torch.zeros(c, dtype=torch.float64, device="cuda")
@@ -1132,8 +1132,8 @@ def test_batchnorm_statistics_folded_into_their_consumers(case, dtype, ws):
     part, ntb = K.bn_bwd_reduce(xt, scale, shift, mean, invstd, to_nhwc(g1, dtype), K.ACT_LRELU, to_nhwc(g2, dtype),
                                 K.ACT_RELU, dy, ws)
     if not K.bn_stats_fused_ok(dtype, c, ntb):          # more partial rows than the default limit: the kernel takes any number
-        assert ntb > 256
-        _lib.lib().pfa_set_knob(14, 1024)
+        assert ntb > 512
+        _lib.lib().pfa_set_knob(14, 4096)
     assert K.bn_stats_fused_ok(dtype, c, ntb)
     lo = torch.float32 if dtype == torch.float32 else torch.bfloat16
     outs = {}

@@ -280,22 +280,37 @@ def test_bf16_mode_tracks_fp32(golden):
             assert int(v) == int(zs[f"step.{sname}.g.{k}"])
 
 
-BF16_STEP_CASES = [  # name, num_downs, ngf, ndf, N, H: BatchNorm populations of at least 8 (small) / 32 (wide) values - with
-    ("small", 5, 8, 8, 2, 32),      # fewer, a last-bit difference in one statistic moves a whole channel
+BF16_STEP_CASES = [  # name, num_downs, ngf, ndf, N, H
+    ("small", 5, 8, 8, 2, 32),
     ("wide", 5, 16, 16, 2, 64),
 ]
 
 
+@pytest.mark.parametrize("route", ["fused", "unfused"])
 @pytest.mark.parametrize("case", BF16_STEP_CASES, ids=[c[0] for c in BF16_STEP_CASES])
-def test_bf16_step_matches_the_bf16_storage_step_oracle(case):
+def test_bf16_step_matches_the_bf16_storage_step_oracle(case, route, monkeypatch):
     """The throughput mode's WHOLE STEP, gated tightly: GanTrainer(precision="bf16") against oracle/bf16.py - forward,
     backward and Adam with a bf16 rounding at the engines' storage points (anchored to the pinned float32 oracle by
-    tests/test_oracle_golden.py).  What is left between the two is the order of float32 sums, rounding ties and the
-    activation knife-edges a tie can flip: losses <= 1e-3 relative, every conv weight gradient <= 1e-2 in relative L2, the
-    BatchNorm buffers and counters, and Adam - whose first step moves a parameter by +-lr whatever the gradient's size, so
-    one flipped sign is a whole step - moving >= 99 % of the parameters alike (train_gan.py:52-71)."""
+    tests/test_oracle_golden.py; the float32 reference itself is 10-20 % away from any bf16 evaluation of these gradients,
+    SURVEY F4).  Both routes of the backward are held: "unfused" (PFA_FUSE_BWD=0: every input gradient is stored before the
+    activation backward of its node) and the default, where launches that can carry the fused backward epilogue do.
+      small   every kernel of the step sums in the oracle's order: the un-fused route agrees to float32 round-off (1e-5) -
+              losses, every weight gradient; a rounding point the engine has and the oracle lacks (or the reverse) cannot hide
+      wide    the stride-1 patch kernel takes over c4 (another order of the float32 sums: a few last-bit differences in the
+              forward).  Generator gradients <= 1.5e-2 in relative L2; the discriminator's <= 5e-2 per pass: at the default
+              initialisation its logit gradients are nearly constant over the map, so the BatchNorm backward of c4 subtracts
+              almost all of the stored (bf16) dy - what is left carries the rounding noise of the stored tensor amplified
+              ~10-20x, in the engine and in the oracle alike, with a different noise pattern as soon as one bit differs
+    Losses <= 1e-3 relative (observed <= 5e-5), BatchNorm buffers and counters, and Adam - whose first step moves a
+    parameter by +-lr whatever the gradient's size, so one flipped sign is a whole step - moving >= 99 % of the parameters
+    alike (train_gan.py:52-71)."""
     from oracle import bf16 as o16
+    from pfa_gan import kernels as K
     name, nd, ngf, ndf, n, h = case
+    unfused = route == "unfused"
+    if unfused:
+        monkeypatch.setattr(K, "FUSE_BWD", False)
+    exact = unfused and name == "small"
     gst = fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False)
     dst = fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False)
     a = fill.uniform(f"bf16step.{name}.a", (n, 3, h, h))
@@ -307,31 +322,29 @@ def test_bf16_step_matches_the_bf16_storage_step_oracle(case):
     tr = pfa_gan.GanTrainer(G, D, precision="bf16")
     losses = tr.step(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
     og, od = {k: v.copy() for k, v in gst.items()}, {k: v.copy() for k, v in dst.items()}
-    ld, lg, ex = o16.gan_step(og, od, ostep.new_adam_state(og), ostep.new_adam_state(od), a, b, nd, 3)
-    assert abs(losses[0] - ld) <= 1e-3 * abs(ld), (losses, ld)
-    assert abs(losses[1] - lg) <= 1e-3 * abs(lg), (losses, lg)
+    ld, lg, ex = o16.gan_step(og, od, ostep.new_adam_state(og), ostep.new_adam_state(od), a, b, nd, 3, unfused=unfused)
+    ltol = 2e-6 if exact else 1e-3
+    assert abs(losses[0] - ld) <= ltol * abs(ld), (losses, ld)
+    assert abs(losses[1] - lg) <= ltol * abs(lg), (losses, lg)
     fake = pfa_gan.kernels.unpack_nchw(tr.gctx.v["fake"], 3).cpu().numpy()
     dfake = np.abs(fake - ex["fake_b"])
     # (a tanh output near +-1 has a bf16 ulp of 2^-8: a last-bit difference upstream moves many of them by one ulp)
-    assert dfake.mean() < 1e-3 and dfake.max() <= 2.0 ** -6, (dfake.mean(), dfake.max())
-    # raw gradients: the generator's arena; the discriminator's two arenas (real | fake pass) summed
+    assert dfake.mean() < (1e-6 if exact else 1e-3) and dfake.max() <= 2.0 ** -6, (dfake.mean(), dfake.max())
     torch.cuda.synchronize()
+    g_tol, d_tol = (1e-5, 1e-5) if exact else (1.5e-2, 5e-2)
     for k, p in G.named_parameters():
         want = ex["g_grads"][k]
-        got = p.grad.cpu().numpy()
         if want.ndim == 4:
-            rel = np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
-            assert rel <= 1e-2, f"G grad {k}: rel L2 {rel:.2e}"
-    # (the discriminator's two passes are held one by one: their gradients largely cancel in the sum Adam takes - real pushes
-    # the logits up, fake down - which would inflate the relative error of the sum)
+            rel = np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
+            assert rel <= g_tol, f"G grad {k}: rel L2 {rel:.2e}"
+    # (the discriminator's two passes one by one: their gradients largely cancel in the sum Adam takes)
     flat_d, g2 = tr.opt_d.flat(), tr.opt_d.grad2()
     for k, p in D.named_parameters():
         o, cnt = flat_d.slots[id(p)]
         for what, got, want in (("fake", p.grad, ex["d_grads_fake"][k]), ("real", flat_d._view(g2, p, o, cnt), ex["d_grads_real"][k])):
             if want.ndim == 4:
-                got = got.cpu().numpy()
-                rel = np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
-                assert rel <= 1e-2, f"D({what}) grad {k}: rel L2 {rel:.2e}"
+                rel = np.linalg.norm(got.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-20)
+                assert rel <= d_tol, f"D({what}) grad {k}: rel L2 {rel:.2e}"
     for mod, ref in ((G, og), (D, od)):
         alike = total = 0
         for k, v in mod.state_dict().items():
@@ -343,7 +356,7 @@ def test_bf16_step_matches_the_bf16_storage_step_oracle(case):
                 total += ref[k].size
             else:
                 assert_close(got, ref[k], 1e-4, 2e-3, f"buffer {k}")
-        assert alike >= 0.99 * total, f"only {alike / total:.2%} of the parameters moved as in the bf16 step oracle"
+        assert alike >= (0.9999 if exact else 0.99) * total, f"only {alike / total:.2%} of the parameters moved as in the bf16 step oracle"
 
 
 def test_gpu_input_without_library_path_is_an_error(monkeypatch):
