@@ -27,9 +27,10 @@ from ._lib import PfaError
 # Outermost levels whose parameter gradients - the last work of a backward pass - run on the main stream instead of behind
 # the side stream's backlog (the main stream would only wait for that stream).  Same-box A/B of the step: discriminator 0 ->
 # 3.22 ms, 1 -> 3.18; generator 0 / 1: within noise in round 2; with the last bucket's update on the main stream (round 3:
-# the main stream then waits for the side stream's LAST weight gradient anyway) 1 is worth +0.67 % (three same-box pairs).
+# the main stream then waits for the side stream's LAST weight gradient anyway) 1 is worth +0.67 % and 2 another +0.67 %
+# (3: +0.2 % only; discriminator 2: -1.3 %; three same-box runs per arm, tools/ab.py).
 D_WGRAD_MAIN_LEVELS = int(os.environ.get("PFA_D_WGRAD_MAIN_LEVELS", "1"))
-G_WGRAD_MAIN_LEVELS = int(os.environ.get("PFA_G_WGRAD_MAIN_LEVELS", "1"))
+G_WGRAD_MAIN_LEVELS = int(os.environ.get("PFA_G_WGRAD_MAIN_LEVELS", "2"))
 
 class FlatParams:
     """One float32 arena for all parameters of a module (+ a gradient arena of the same shape)."""
