@@ -766,7 +766,7 @@ class DiscriminatorEngine(_Engine):
         return self.flat.slots[id(L.w)][0], n - 2
 
     def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None,
-                 fresh=True, bucket_ready=None):
+                 fresh=True, bucket_ready=None, bucket_done=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55).
         need_dx: return dL/d(input) [B,H,W,sum(in_pad)]; with dx_part=i only the gradient of input source i
@@ -774,18 +774,21 @@ class DiscriminatorEngine(_Engine):
         fresh: garena holds zeros where this pass writes weight gradients (False for a second pass that accumulates into the
         arena of a first one).
         bucket_ready(): called when every kernel that writes grad_bucket()'s range has been issued (the caller may all-reduce
-        that range under the rest of the backward)."""
+        that range under the rest of the backward).
+        bucket_done(): called when, in addition, every kernel that READS the parameters of that range has been issued - behind
+        the input gradient of the range's outermost layer (the caller may update them under the rest of the backward)."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
         K.set_phase(True)
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:
-            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh, bucket_ready)
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh, bucket_ready, bucket_done)
         finally:
             self.ws_cur = self.ws
 
-    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True, bucket_ready=None):
+    def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True, bucket_ready=None,
+                  bucket_done=None):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -861,4 +864,6 @@ class DiscriminatorEngine(_Engine):
                         K.gather_gemm(mode, [dr], wb, cp, [g], grid, self.ws_cur)
                     if i == 0:
                         dx = g
+            if bucket_done is not None and i == n - 2:
+                bucket_done()
         return dx

@@ -28,6 +28,7 @@ D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s
 DREAL_WGRAD_SIDE = _os.environ.get("PFA_DREAL_WGRAD_SIDE", "0") != "0"   # D(real)'s weight gradients on side2 instead of in line
 D_EARLY_REDUCE = _os.environ.get("PFA_D_EARLY_REDUCE", "1") != "0"     # data parallel: D's gradients reduced as they become final
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
+BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "1") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase (A/B switch)
 EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
@@ -119,17 +120,19 @@ class FusedAdam(torch.optim.Optimizer):
             self._dev_steps += 1
 
     @torch.no_grad()
-    def step_range(self, lo, hi, grad_scale=1.0):
+    def step_range(self, lo, hi, grad_scale=1.0, use_grad2=False):
         """Adam on elements [lo, hi) of the arena (16-byte aligned bounds: parameter starts) with the step count of the
-        last step_begin().  The fused trainer updates a bucket as soon as its gradients are final."""
+        last step_begin().  The fused trainer updates a bucket as soon as its gradients are final.  use_grad2: the gradient
+        is the sum of the two arenas (the discriminator's real | fake passes)."""
         flat = self.flat()
         g = self.param_groups[0]
+        g2 = self._grad2[lo:hi] if use_grad2 else None
         if getattr(self, "_range_dev", False):
             K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
-                   g["eps"], 0, step_dev=self.step_dev, grad_scale=grad_scale)
+                   g["eps"], 0, step_dev=self.step_dev, grad_scale=grad_scale, g2=g2)
             return
         K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
-               g["eps"], self.steps, grad_scale=grad_scale)
+               g["eps"], self.steps, grad_scale=grad_scale, g2=g2)
 
     def state_dict(self):
         self.flat()
@@ -313,12 +316,32 @@ class GanTrainer:
             with torch.cuda.stream(self.side2):
                 self._d_works.append(self._reduce(garena[d_lo:], ("d", 0), async_op=True))
         bucketed_d = early_reduce
+        # One GPU: the discriminator is updated bucket by bucket like the generator - c4 / c5 (76 % of it) on side2 as soon
+        # as their gradients are final and their weights have been read for the last time (behind c4's input gradient),
+        # under the rest of the backward; only c1 .. c3 are left for the main stream between the D phase and the generator
+        # phase's discriminator pass, which waits for this update.
+        self._d_updated = False
+        update_d = (BUCKET_UPDATE_D and self.pg is None and not D_WGRAD_PAIR and d_lo > 0 and (not graph_safe or self._listing))
+
+        def d_update():
+            K.wait_stream(self.side2, main)
+            K.wait_stream(self.side2, self.side)          # (D(real)'s arena: complete long ago)
+            with torch.cuda.stream(self.side2):
+                self.opt_d.step_range(d_lo, self.opt_d.flat().total, grad_scale=1.0, use_grad2=True)
+                Dn.refresh_shadows_range(d_lo, self.opt_d.flat().total)
+        if update_d:
+            self.opt_d.step_begin(graph_safe)
         Dn.backward(self.ctx_f, dl_f, garena, param_grads=True, side=(self.side2, self.side) if D_WGRAD_PAIR else self.side2,
-                    bucket_ready=d_bucket if bucketed_d else None)
+                    bucket_ready=d_bucket if bucketed_d else None, bucket_done=d_update if update_d else None)
         self._mark("D(fake) backward chain done")
         K.wait_stream(main, self.side)
         K.wait_stream(main, self.side2)
         self._mark("D gradients complete")
+        if update_d:
+            self.opt_d.step_range(0, d_lo, grad_scale=1.0, use_grad2=True)
+            Dn.refresh_shadows_range(0, d_lo)
+            Dn.shadows_refreshed()
+            self._d_updated = True
         if bucketed_d:                       # what is left: c1 .. c3 (and D(real)'s arena, reduced above)
             if d_lo > 0:                     # (n_layers = 1: the bucket already is the whole arena)
                 self._d_works.append(self._reduce(garena[:d_lo], ("d", 1), async_op=True))
@@ -328,8 +351,11 @@ class GanTrainer:
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
-        self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=True)
-        Dn.refresh_shadows(force=True)
+        if getattr(self, "_d_updated", False):        # already updated bucket by bucket during the D phase
+            self._d_updated = False
+        else:
+            self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=True)
+            Dn.refresh_shadows(force=True)
         self._mark("Adam(D) done")
         if self.side is None or not EARLY_G_ZERO:
             self.opt_g.zero_grad()
