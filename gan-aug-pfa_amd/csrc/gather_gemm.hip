@@ -1117,6 +1117,15 @@ extern "C" int pfa_gather_timing_get(int i, float* ms, const char** name, double
     return 0;
 }
 
+extern "C" int pfa_gather_timing_start(int i, int ref, float* start_ms) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    PFA_REQUIRE(i >= 0 && i < (int)g_timed.size() && ref >= 0 && ref < (int)g_timed.size() && start_ms,
+                "pfa_gather_timing_start: bad arguments");
+    hipError_t e = hipEventElapsedTime(start_ms, g_timed[ref].e0, g_timed[i].e0);    // (events of different streams compare)
+    if (e != hipSuccess) PFA_FAIL((int)e, "pfa_gather_timing_start: %s (synchronise first)", hipGetErrorString(e));
+    return 0;
+}
+
 void* g_pfa_dbgbuf = nullptr;
 size_t g_pfa_dbgbuf_bytes = 0;
 extern "C" int pfa_set_debug_buffer(void* dev, size_t bytes) {

@@ -28,8 +28,9 @@ D_WGRAD_PAIR = _os.environ.get("PFA_D_WGRAD_PAIR", "0") != "0"       # D(fake)'s
 DREAL_WGRAD_SIDE = _os.environ.get("PFA_DREAL_WGRAD_SIDE", "0") != "0"   # D(real)'s weight gradients on side2 instead of in line
 D_EARLY_REDUCE = _os.environ.get("PFA_D_EARLY_REDUCE", "1") != "0"     # data parallel: D's gradients reduced as they become final
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
-BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "1") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase (A/B switch)
+BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "0") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase: measured -0.7 % (its range update queues in front of D(fake)'s remaining weight gradients on side2): off
 EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
+DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "1") != "0"   # A/B switch, see GanTrainer._d_update_g_phase
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
@@ -394,6 +395,22 @@ class GanTrainer:
             self.opt_g.step_begin(graph_safe)
             scale = 1.0 / self.world
 
+            whens = G.grad_buckets()[1]
+            pending = []          # buckets whose gradients are final (and, data parallel, on their way) but not yet updated
+
+            def update(ranges):
+                """Adam + shadow refresh of gradient ranges on the current stream, contiguous ranges in one launch."""
+                ranges = sorted(ranges)
+                merged = [list(ranges[0])]
+                for lo, hi in ranges[1:]:
+                    if lo == merged[-1][1]:
+                        merged[-1][1] = hi
+                    else:
+                        merged.append([lo, hi])
+                for lo, hi in merged:
+                    self.opt_g.step_range(lo, hi, grad_scale=scale)
+                    G.refresh_shadows_range(lo, hi)
+
             def hook(i):
                 lo, hi = buckets[i]
                 if hi <= lo:
@@ -405,18 +422,35 @@ class GanTrainer:
                     K.wait_stream(main, self.side)
                     if self.pg is not None:
                         self._reduce(garena[lo:hi], ("g", i), async_op=True).wait()
-                    self.opt_g.step_range(lo, hi, grad_scale=scale)
-                    G.refresh_shadows_range(lo, hi)
+                    if pending:                                  # (nothing is left pending in the default layout)
+                        K.wait_stream(main, self.side2)
+                        for _, _, w in pending:
+                            if w is not None:
+                                w.wait()
+                    update([(lo, hi)] + [(a, b) for a, b, _ in pending])
+                    del pending[:]
                     return
                 K.wait_stream(self.side2, main)
                 K.wait_stream(self.side2, self.side)
                 with torch.cuda.stream(self.side2):
+                    work = None
                     if self.pg is not None:
                         # enqueued behind side2, runs on the communicator's stream; side2 (not the weight-gradient
-                        # stream) waits for it
-                        self._reduce(garena[lo:hi], ("g", i), async_op=True).wait()
-                    self.opt_g.step_range(lo, hi, grad_scale=scale)
-                    G.refresh_shadows_range(lo, hi)
+                        # stream) waits for it - when it updates the range
+                        work = self._reduce(garena[lo:hi], ("g", i), async_op=True)
+                    pending.append((lo, hi, work))
+                    # Adam is HBM-bound (28 B per parameter at ~5.7 TB/s) and so are the chain's launches on the small
+                    # maps - the decoder's and encoder's innermost levels stream 8-34 MB of weights each: beside a range
+                    # update they took 80-100 us instead of 13-20 (tools/insitu_gantt.py).  The decoder's buckets
+                    # therefore wait (their all-reduce does not) until the chain is back on the large maps, i.e. for the
+                    # first encoder hook; from there on every bucket is updated as it becomes final.
+                    if DEFER_DECODER_UPDATE and whens[i][0] == "dec":
+                        return
+                    for _, _, w in pending:
+                        if w is not None:
+                            w.wait()
+                    update([(a, b) for a, b, _ in pending])
+                    del pending[:]
         elif self.pg is not None and self.side is not None and not graph_safe:
             def hook(i):
                 # bucket i is complete once the side stream (weight gradients) and the main stream (BatchNorm

@@ -97,6 +97,9 @@ const char* pfa_last_gather_kernel(void);
 int pfa_gather_timing(int enable);
 int pfa_gather_timing_count(void);
 int pfa_gather_timing_get(int i, float* ms, const char** name, double* flop, double* bytes, int* splitk);
+/* Start of timed launch i relative to the start of timed launch `ref`, in ms (launches of different streams compare: the
+ * events are device timestamps) - an in-situ timeline of the MFMA kernels of a multi-stream step (tools/insitu_gantt.py). */
+int pfa_gather_timing_start(int i, int ref, float* start_ms);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA
  * out[pix(m)][n] = act( bias[n] + sum_{tap,c} src[pix(m)+tap][c] * w[n][tap][c] )
