@@ -30,7 +30,7 @@ D_EARLY_REDUCE = _os.environ.get("PFA_D_EARLY_REDUCE", "1") != "0"     # data pa
 BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + shadow refresh bucket by bucket under the backward
 BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "0") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase: measured -0.7 % (its range update queues in front of D(fake)'s remaining weight gradients on side2): off
 EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
-DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "1") != "0"   # A/B switch, see GanTrainer._d_update_g_phase
+DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"   # measured -2.0 %: off (see GanTrainer._d_update_g_phase)
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
