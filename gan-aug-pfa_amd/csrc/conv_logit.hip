@@ -48,6 +48,10 @@ struct LogitK {
     int nb, h, w, c, ld, act;
     float slope;
     int xtiles, rgroups;
+    // forward with the BCE-with-logits loss in its epilogue (pfa_logit_fwd_bce): dlogits out, one loss partial per workgroup
+    char* bce_dl;
+    float* bce_parts;
+    float bce_target, bce_lscale, bce_gscale;
 };
 
 // ------------------------------------------------------------------ forward
@@ -111,12 +115,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int ox = ox0 + 2 * wave;
     const float bias = p.bias ? p.bias[0] : 0.f;
     // lane 0 / lane 1 write the two logits: channel 0 the value, the pad channels zeros
+    float term = 0.f;
     if (lane < 2 && ox + lane < wo) {
         bf16x8 o = {};
         o[0] = (bf16_t)((lane ? a1 : a0) + bias);
-        char* dst = p.out + (((size_t)(n * ho + oy) * wo + ox + lane) * p.ld) * 2;
+        const size_t off = (((size_t)(n * ho + oy) * wo + ox + lane) * p.ld) * 2;
+        char* dst = p.out + off;
         *(bf16x8*)dst = o;
         for (int k = 8; k < p.ld; k += 8) *(bf16x8*)(dst + k * 2) = bf16x8{};
+        if (p.bce_dl) {
+            // BCEWithLogitsLoss on the STORED logit, as k_bce_logits forms it (train_gan.py:42,58,60,67): the loss term and
+            // dloss/dlogit = gscale (sigmoid(x) - t) / count, in the dlogits layout (value in channel 0)
+            const float x = (float)o[0], cnt = (float)((size_t)p.nb * ho * wo);
+            term = fmaxf(x, 0.f) - x * p.bce_target + log1pf(expf(-fabsf(x)));
+            bf16x8 g = {};
+            g[0] = (bf16_t)(p.bce_gscale * (1.f / (1.f + expf(-x)) - p.bce_target) / cnt);
+            char* gd = p.bce_dl + off;
+            *(bf16x8*)gd = g;
+            for (int k = 8; k < p.ld; k += 8) *(bf16x8*)(gd + k * 2) = bf16x8{};
+        }
+    }
+    if (p.bce_parts) {                           // one partial per workgroup, its 16 terms added in a fixed order
+        __shared__ float terms[16];
+        if (lane < 2) terms[2 * wave + lane] = term;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += terms[i];
+            p.bce_parts[blockIdx.x] = p.bce_lscale * t / (float)((size_t)p.nb * ho * wo);
+        }
     }
 }
 
@@ -355,12 +383,29 @@ static int logit_common(LogitK& k, int nb, int h, int w, int c, int ld) {
     return 0;
 }
 
+extern "C" int pfa_logit_fwd_nparts(int nb, int h, int wd) { return nb * (h - 1) * ((wd - 1 + FT - 1) / FT); }
+
+static int logit_fwd_launch(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c, int ld,
+                            void* dlogits, float* parts, float target, float lscale, float gscale, pfa_stream s);
+
 extern "C" int pfa_logit_fwd(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c,
                              int ld, pfa_stream s) {
+    return logit_fwd_launch(x, w, bias, logits, nb, h, wd, c, ld, nullptr, nullptr, 0.f, 0.f, 0.f, s);
+}
+
+extern "C" int pfa_logit_fwd_bce(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c,
+                                 int ld, float target, float lscale, float gscale, float* parts, void* dlogits, pfa_stream s) {
+    PFA_REQUIRE(parts && dlogits, "pfa_logit_fwd_bce: needs the partials buffer and the dlogits tensor");
+    return logit_fwd_launch(x, w, bias, logits, nb, h, wd, c, ld, dlogits, parts, target, lscale, gscale, s);
+}
+
+static int logit_fwd_launch(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c, int ld,
+                            void* dlogits, float* parts, float target, float lscale, float gscale, pfa_stream s) {
     PFA_REQUIRE(x && w && logits, "pfa_logit_fwd: null pointer");
     LogitK k{};
     if (int rc = logit_common(k, nb, h, wd, c, ld)) return rc;
     k.x = (const char*)x; k.wt = (const bf16_t*)w; k.bias = bias; k.out = (char*)logits;
+    k.bce_dl = (char*)dlogits; k.bce_parts = parts; k.bce_target = target; k.bce_lscale = lscale; k.bce_gscale = gscale;
     k.xtiles = (wd - 1 + FT - 1) / FT;
     constexpr int LDS = 4 * FPW * 1024;
     static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)

@@ -33,6 +33,10 @@ struct ScatterK {
     float slope;
     int ty_tiles, tx_tiles;
     int kchunks, k1chunks;   // 128-byte K chunks in total / coming from src1
+    const char* l1_fake;     // fused L1 + Tanh' epilogue (pfa_hip.h), or NULL
+    const char* l1_real;
+    float l1_scale;
+    int l1_creal;
 };
 
 template <typename T> struct Mma;
@@ -207,16 +211,27 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
                         v[e] += q[0]; v[e + 1] += q[1]; v[e + 2] += q[2]; v[e + 3] += q[3];
                     }
                 }
-            T* op = (T*)p.out + ((size_t)(img * HO + oy) * WO + ox) * p.ld;
+            const size_t orow = ((size_t)(img * HO + oy) * WO + ox) * p.ld;
+            T* op = (T*)p.out + orow;
 #pragma unroll
             for (int e0 = 0; e0 < 8; e0 += CH) {            // the padded row is 4 (f32) or 8 elements wide at most
                 if (e0 >= p.ld) break;
-                Chunk<T> o;
+                Chunk<T> o, f, rl;
+                if (p.l1_fake) {
+                    f.load((const T*)p.l1_fake + orow + e0);
+                    rl.load((const T*)p.l1_real + orow + e0);
+                }
 #pragma unroll
                 for (int e = 0; e < CH; ++e) {
                     const int c = e0 + e;
                     float t = 0.f;                           // pad lanes are exact zeros
                     if (c < NCO && c < p.n) t = apply_act(v[c < NCO ? c : 0] + bv[c < NCO ? c : 0], p.act, p.slope);
+                    if (p.l1_fake) {                         // dpre from dL/dfake as it would have been stored (pfa_l1_tanh_bwd)
+                        const float dgan = to_f32(from_f32<T>(t));
+                        const float df = f.v[e] - rl.v[e];
+                        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                        t = c < p.l1_creal ? (p.l1_scale * sgn + dgan) * (1.f - f.v[e] * f.v[e]) : 0.f;
+                    }
                     o.v[e] = t;
                 }
                 o.store(op + e0);
@@ -268,6 +283,10 @@ extern "C" int pfa_tconv_scatter(const pfa_scatter_args* a, pfa_stream s) {
     k.nb = a->nb; k.hs = a->hs; k.ws = a->ws;
     k.c1 = a->c1; k.c2 = a->c2; k.ctot = a->c1 + a->c2;
     k.n = a->n; k.ld = a->ld; k.act = a->act; k.slope = a->slope;
+    PFA_REQUIRE((a->l1_fake == nullptr) == (a->l1_real == nullptr), "pfa_tconv_scatter: l1_fake and l1_real come together");
+    PFA_REQUIRE(!a->l1_fake || (a->act == PFA_ACT_NONE && !a->bias && a->l1_creal > 0 && a->l1_creal <= a->n),
+                "pfa_tconv_scatter: the fused L1 epilogue takes a plain input-gradient launch (no bias / activation), 0 < l1_creal <= n");
+    k.l1_fake = (const char*)a->l1_fake; k.l1_real = (const char*)a->l1_real; k.l1_scale = a->l1_scale; k.l1_creal = a->l1_creal;
     k.ty_tiles = (a->hs + PH - 3) / (PH - 2);
     k.tx_tiles = (a->ws + PW - 3) / (PW - 2);
     const int kch = 8 * pfa_ch(a->dtype);

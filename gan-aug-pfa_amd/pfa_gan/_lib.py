@@ -48,6 +48,7 @@ class ScatterArgs(Structure):
         ("c1", c_int32), ("c2", c_int32), ("n", c_int32), ("ld", c_int32), ("act", c_int32), ("slope", c_float),
         ("reserved", c_int32),
         ("src1", c_void_p), ("src2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
+        ("l1_fake", c_void_p), ("l1_real", c_void_p), ("l1_scale", c_float), ("l1_creal", c_int32),
     ]
 
 
@@ -82,6 +83,9 @@ PROTOTYPES = {
     "pfa_wgrad_slices": (c_int, [POINTER(WgradArgs)]),
     "pfa_logit_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "pfa_logit_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "pfa_logit_fwd_nparts": (c_int, [c_int, c_int, c_int]),
+    "pfa_logit_fwd_bce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                  c_float, c_void_p, c_void_p, c_void_p]),
     "pfa_logit_dgrad_tiles": (c_int, [c_int, c_int, c_int]),
     "pfa_logit_dgrad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                 c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

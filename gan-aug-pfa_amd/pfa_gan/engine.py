@@ -29,6 +29,7 @@ from ._lib import PfaError
 # 3.22 ms, 1 -> 3.18; generator 0 / 1: within noise in round 2; with the last bucket's update on the main stream (round 3:
 # the main stream then waits for the side stream's LAST weight gradient anyway) 1 is worth +0.67 % and 2 another +0.67 %
 # (3: +0.2 % only; discriminator 2: -1.3 %; three same-box runs per arm, tools/ab.py).
+BCE_FUSED = os.environ.get("PFA_BCE_FUSED", "1") != "0"      # the loss in the logit layer's launch (A/B switch)
 D_WGRAD_MAIN_LEVELS = int(os.environ.get("PFA_D_WGRAD_MAIN_LEVELS", "1"))
 G_WGRAD_MAIN_LEVELS = int(os.environ.get("PFA_G_WGRAD_MAIN_LEVELS", "2"))
 
@@ -715,11 +716,15 @@ class DiscriminatorEngine(_Engine):
     def _out_hw(L, h, w):
         return (h // 2, w // 2) if L.stride == 2 else (h - 1, w - 1)
 
-    def forward(self, srcs, ctx, train=True):
-        """srcs: list of NHWC tensors matching in_split.  Returns logits NHWC [B,ho,wo,cp(1)]."""
+    def forward(self, srcs, ctx, train=True, bce=None):
+        """srcs: list of NHWC tensors matching in_split.  Returns logits NHWC [B,ho,wo,cp(1)].
+        bce = (target, lscale, gscale, parts): BCE-with-logits of the pass (train_gan.py:58,60,67) - where the logit layer
+        runs on its vector kernel the loss rides in that launch's epilogue: ctx.v["bce_nparts"] then holds the number of loss
+        partials written to `parts` and ctx.buf("dlogits") the gradient; otherwise ctx.v["bce_nparts"] is None and the caller
+        runs kernels.bce_logits_parts on the returned logits."""
         dt = self.dtype
         B, H, W, _ = srcs[0].shape
-        ctx.v.update(srcs=list(srcs), a={}, train=train)
+        ctx.v.update(srcs=list(srcs), a={}, train=train, bce_nparts=None)
         K.set_phase(train)
         a, h, w = list(srcs), H, W
         n = len(self.layers)
@@ -734,7 +739,12 @@ class DiscriminatorEngine(_Engine):
             if L.bn is None:
                 out = ctx.buf(f"c{i}.a", shape, dt)
                 if self._logit_layer(i, a):
-                    K.logit_fwd(a[0], L.same, L.b, out)
+                    if bce is not None and BCE_FUSED:
+                        target, lscale, gscale, parts = bce
+                        ctx.v["bce_nparts"] = K.logit_fwd_bce(a[0], L.same, L.b, out, target, lscale, gscale, parts,
+                                                              ctx.buf("dlogits", shape, dt))
+                    else:
+                        K.logit_fwd(a[0], L.same, L.b, out)
                 else:
                     K.gather_gemm(mode, a, L.w_fwd, L.cout, [out], (B, ho, wo), self.ws, bias=L.b,
                                   act=K.ACT_LRELU if i < n - 1 else K.ACT_NONE, c_real=sum(L.in_real))
@@ -766,7 +776,7 @@ class DiscriminatorEngine(_Engine):
         return self.flat.slots[id(L.w)][0], n - 2
 
     def backward(self, ctx, dlogits, garena, param_grads=True, need_dx=False, side=None, alt_ws=False, dx_part=None,
-                 fresh=True, bucket_ready=None, bucket_done=None):
+                 fresh=True, bucket_ready=None, bucket_done=None, dx_l1=None):
         """dlogits NHWC.  param_grads=False is the generator phase: input gradient only (the reference
         computes and discards D's weight gradients there, train_gan.py:70 then :55).
         need_dx: return dL/d(input) [B,H,W,sum(in_pad)]; with dx_part=i only the gradient of input source i
@@ -776,19 +786,33 @@ class DiscriminatorEngine(_Engine):
         bucket_ready(): called when every kernel that writes grad_bucket()'s range has been issued (the caller may all-reduce
         that range under the rest of the backward).
         bucket_done(): called when, in addition, every kernel that READS the parameters of that range has been issued - behind
-        the input gradient of the range's outermost layer (the caller may update them under the rest of the backward)."""
+        the input gradient of the range's outermost layer (the caller may update them under the rest of the backward).
+        dx_l1 = (fake, real, c_real, lambda, out): the generator phase - the launch that computes dL/dfake writes, into `out`,
+        the gradient w.r.t. the generator's pre-Tanh output instead (kernels.tconv_scatter(l1=...)) and backward returns `out`;
+        ignored (None returned through dx as usual) when that launch is not the scatter kernel: check l1_fused()."""
         if not ctx.v.get("train", False):
             raise PfaError("discriminator backward needs a training-mode forward")
         K.set_phase(True)
         # alt_ws: this whole pass runs on a stream of its own, concurrently with another pass of the same engine
         self.ws_cur = self.ws_alt if alt_ws else self.ws
         try:
-            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh, bucket_ready, bucket_done)
+            return self._backward(ctx, dlogits, garena, param_grads, need_dx, side, dx_part, fresh, bucket_ready, bucket_done,
+                                  dx_l1)
         finally:
             self.ws_cur = self.ws
 
+    def l1_fused(self, ctx, dx_part):
+        """Will backward(..., dx_part=, dx_l1=...) of this context's pass take the fused L1 / Tanh' epilogue?  (the first
+        layer's input gradient onto one source of <= 8 channels through the scatter kernel)"""
+        L = self.layers[0]
+        out = ctx.v["a"][0]
+        if dx_part is None or L.stride != 2:
+            return False
+        cp = L.in_pad[dx_part]
+        return K.SCATTER and bool(K.lib().pfa_tconv_scatter_supported(K.dt_code(self.dtype), out.shape[3], 0, cp, cp))
+
     def _backward(self, ctx, dlogits, garena, param_grads, need_dx, side, dx_part=None, fresh=True, bucket_ready=None,
-                  bucket_done=None):
+                  bucket_done=None, dx_l1=None):
         dt = self.dtype
         v = ctx.v
         n = len(self.layers)
@@ -857,9 +881,13 @@ class DiscriminatorEngine(_Engine):
                         r0 = sum(L.in_pad[:dx_part])
                         cp = L.in_pad[dx_part]
                         wb = wb[r0:r0 + cp]
-                    g = ctx.buf(f"g.c{i}" if dx_part is None or i else f"g.c0.{dx_part}", (B, hin, win, cp), dt)
+                    use_l1 = i == 0 and dx_l1 is not None and dx_part is not None
+                    g = dx_l1[4] if use_l1 else ctx.buf(f"g.c{i}" if dx_part is None or i else f"g.c0.{dx_part}",
+                                                        (B, hin, win, cp), dt)
                     if L.stride == 2 and K.tconv_scatter_ok([dr], cp, g):
-                        K.tconv_scatter([dr], wb, cp, g)
+                        K.tconv_scatter([dr], wb, cp, g, l1=dx_l1[:4] if use_l1 else None)
+                    elif use_l1:
+                        raise PfaError("discriminator backward: dx_l1 needs the scatter kernel on the first layer (l1_fused())")
                     else:
                         K.gather_gemm(mode, [dr], wb, cp, [g], grid, self.ws_cur)
                     if i == 0:

@@ -283,9 +283,11 @@ def tconv_scatter_ok(srcs, n, out):
     return bool(lib().pfa_tconv_scatter_supported(dt_code(srcs[0].dtype), srcs[0].shape[3], c2, n, out.shape[3]))
 
 
-def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE):
+def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE, l1=None):
     """out = act(bias + ConvTranspose2d_{k4,s2,p1}([srcs]))) for n <= 8 output channels: pointwise MFMA GEMM per input
-    patch + col2im in LDS (csrc/tconv_scatter.hip).  Same operands and result as gather_gemm(TCONV_S2, ...)."""
+    patch + col2im in LDS (csrc/tconv_scatter.hip).  Same operands and result as gather_gemm(TCONV_S2, ...).
+    l1 = (fake, real, c_real, lambda): the generator phase's fused epilogue - `out` receives dL/dpre of the generator's
+    output layer, what l1_tanh_bwd computes from the stored dL/dfake (see pfa_hip.h)."""
     _require_cuda(*srcs, w, out)
     a = ScatterArgs()
     a.struct_size = ctypes.sizeof(ScatterArgs)
@@ -297,6 +299,14 @@ def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE):
     a.act, a.slope = act, SLOPE
     a.src1, a.src2 = ptr(srcs[0]), ptr(srcs[1]) if len(srcs) > 1 else None
     a.w, a.bias, a.out = ptr(w), ptr(bias), ptr(out)
+    if l1 is not None:
+        fake, real, c_real, lam = l1
+        if fake.shape != out.shape or real.shape != out.shape:
+            raise _lib.PfaError("tconv_scatter: the fused L1 epilogue needs fake / real of the output's shape")
+        a.l1_fake, a.l1_real, a.l1_creal = ptr(fake), ptr(real), c_real
+        # lambda * (1 / (pixels * c_real)) in float32, the way pfa_l1_tanh_bwd forms it: the two routes give the same bits
+        f32 = __import__("numpy").float32
+        a.l1_scale = float(f32(lam) * (f32(1.0) / (f32(rows_of(out)) * f32(c_real))))
     check(lib().pfa_tconv_scatter(ctypes.byref(a), stream()), "pfa_tconv_scatter")
 
 
@@ -388,6 +398,17 @@ def logit_fwd(x, w, bias, logits):
     B, h, wd, c = x.shape
     check(lib().pfa_logit_fwd(ptr(x), ptr(w), ptr(bias), ptr(logits), B, h, wd, c, logits.shape[3], stream()),
           "pfa_logit_fwd")
+
+
+def logit_fwd_bce(x, w, bias, logits, target, lscale, gscale, parts, dlogits):
+    """logit_fwd + bce_logits_parts in one launch.  -> number of partials written (parts[0 .. n))"""
+    B, h, wd, c = x.shape
+    n = int(lib().pfa_logit_fwd_nparts(B, h, wd))
+    if parts.numel() < n:
+        raise _lib.PfaError("logit_fwd_bce: partials buffer too small")
+    check(lib().pfa_logit_fwd_bce(ptr(x), ptr(w), ptr(bias), ptr(logits), B, h, wd, c, logits.shape[3], float(target),
+                                  float(lscale), float(gscale), ptr(parts), ptr(dlogits), stream()), "pfa_logit_fwd_bce")
+    return n
 
 
 def logit_dgrad(dlogits, w, raw, scale, shift, mean, invstd, act, dy, ws):

@@ -16,6 +16,7 @@ from ._lib import PfaError
 from .engine import FlatParams
 from .models import resolve_dtype
 
+PARTS = 1024           # loss partials per pass (GanTrainer._parts)
 LAMBDA_L1 = 100.0      # train_gan.py:33
 LEARNING_RATE = 1e-4   # train_gan.py:28-29
 BETAS = (0.5, 0.999)   # train_gan.py:30,140-141
@@ -31,6 +32,7 @@ BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + sh
 BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "0") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase: measured -0.7 % (its range update queues in front of D(fake)'s remaining weight gradients on side2): off
 EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
 DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"   # measured -2.0 %: off (see GanTrainer._d_update_g_phase)
+L1_FUSED = _os.environ.get("PFA_L1_FUSED", "1") != "0"               # dL/dpre from the launch that computes dL/dfake (A/B switch)
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
@@ -212,9 +214,9 @@ class GanTrainer:
         self._d_free_recorded = False
         self.inputs_resident = bool(inputs_resident)
         self.marks = None
-        # Loss sums without float atomics: the loss kernels store one partial per workgroup - D(real) | D(fake) | G's BCE (64
-        # each at most) | L1 (1024) - and one launch at the end of the step adds them in index order: the same bits every run.
-        self._parts = torch.zeros(3 * 64 + 1024, dtype=torch.float32, device=dev)
+        # Loss sums without float atomics: the loss kernels store one partial per workgroup - D(real) | D(fake) | G's BCE | L1
+        # (PARTS each at most) - and one launch at the end of the step adds them in index order: the same bits every run.
+        self._parts = torch.zeros(4 * PARTS, dtype=torch.float32, device=dev)
         self._nparts = [0, 0, 0, 0]
         self._graphs = None
         self._listing = False          # launch lists are being warmed up / recorded / replayed (use_graph == "replay")
@@ -241,15 +243,11 @@ class GanTrainer:
             garena2 = self.opt_d.grad2()      # an arena per pass, as on three streams: a second pass ADDING to the first
             self.opt_d.zero_grad()            # one's sums would depend on the order of its float atomics
             fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
-            lr = Dn.forward([xa, xb], self.ctx_r, train=True)
-            dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-            self._nparts[0] = K.bce_logits_parts(lr, 1.0, 0.5, 0.5, parts[0:64], dl_r)
-            lf = Dn.forward([xa, fake], self.ctx_f, train=True)
-            dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
-            self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
+            dl_r = self._d_forward_bce([xa, xb], self.ctx_r, 0, 1.0, 0.5, 0.5)
+            dl_f = self._d_forward_bce([xa, fake], self.ctx_f, 1, 0.0, 0.5, 0.5)
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True)
             Dn.backward(self.ctx_f, dl_f, garena, param_grads=True)
-            K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
+            K.loss_finish(parts, [(0, self._nparts[0]), (PARTS, PARTS + self._nparts[1])], self.losses[0:1])
             return
         # Three streams.  side: the whole D(real) forward + backward (it needs neither the generator nor D(fake)) into
         # the second gradient arena; main: G forward -> D(fake) forward -> D(fake) dgrad/BatchNorm chain; side2: D(fake)'s
@@ -288,9 +286,7 @@ class GanTrainer:
         with torch.cuda.stream(self.side):
             self._mark("side: D(real) begins")
             K.fill_zero(garena2)
-            lr = Dn.forward([xa, xb], self.ctx_r, train=True)
-            dl_r = self.ctx_r.buf("dlogits", lr.shape, lr.dtype)
-            self._nparts[0] = K.bce_logits_parts(lr, 1.0, 0.5, 0.5, parts[0:64], dl_r)
+            dl_r = self._d_forward_bce([xa, xb], self.ctx_r, 0, 1.0, 0.5, 0.5)
             K.record_event(self._ev_real_fwd, self.side)
             self._mark("side: D(real) forward done")
             Dn.backward(self.ctx_r, dl_r, garena2, param_grads=True, alt_ws=True, side=self.side2 if DREAL_WGRAD_SIDE else None)
@@ -302,9 +298,7 @@ class GanTrainer:
         fake = G.forward(xa, self.gctx, train=True, bn_repeats=2)
         self._mark("G forward done")
         K.wait_event(main, self._ev_real_fwd)
-        lf = Dn.forward([xa, fake], self.ctx_f, train=True)
-        dl_f = self.ctx_f.buf("dlogits", lf.shape, lf.dtype)
-        self._nparts[1] = K.bce_logits_parts(lf, 0.0, 0.5, 0.5, parts[64:128], dl_f)
+        dl_f = self._d_forward_bce([xa, fake], self.ctx_f, 1, 0.0, 0.5, 0.5)
         self._mark("D(fake) forward done")
         # (side is free again: D(real) finished under the generator's forward)
         d_lo = Dn.grad_bucket()[0]
@@ -348,7 +342,17 @@ class GanTrainer:
                 self._d_works.append(self._reduce(garena[:d_lo], ("d", 1), async_op=True))
             self._d_reduced = True
         # loss_d of this step (before _ev_d_free: the next step's D(real) may overwrite its partials from there on)
-        K.loss_finish(parts, [(0, self._nparts[0]), (64, 64 + self._nparts[1])], self.losses[0:1])
+        K.loss_finish(parts, [(0, self._nparts[0]), (PARTS, PARTS + self._nparts[1])], self.losses[0:1])
+
+    def _d_forward_bce(self, srcs, ctx, slot, target, lscale, gscale):
+        """Discriminator forward + BCE-with-logits (loss partials into slot `slot` of self._parts, dlogits into the context):
+        one launch fewer where the logit layer's kernel carries the loss (DiscriminatorEngine.forward(bce=)).  -> dlogits"""
+        parts = self._parts[slot * PARTS:(slot + 1) * PARTS]
+        logits = self.Dn.forward(srcs, ctx, train=True, bce=(target, lscale, gscale, parts))
+        dl = ctx.buf("dlogits", logits.shape, logits.dtype)
+        n = ctx.v.get("bce_nparts")
+        self._nparts[slot] = n if n is not None else K.bce_logits_parts(logits, target, lscale, gscale, parts, dl)
+        return dl
 
     def _d_update_g_phase(self, xa, xb, graph_safe):
         G, Dn = self.G, self.Dn
@@ -365,18 +369,26 @@ class GanTrainer:
         # launches plan for the whole chip)
         K.set_solo(True)
         try:
-            lg = Dn.forward([xa, fake], self.ctx_r, train=True)
-            dl_g = self.ctx_r.buf("dlogits", lg.shape, lg.dtype)
-            self._nparts[2] = K.bce_logits_parts(lg, 1.0, 1.0, 1.0, self._parts[128:192], dl_g)
-            dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1)     # dL/dfake only
+            dl_g = self._d_forward_bce([xa, fake], self.ctx_r, 2, 1.0, 1.0, 1.0)
+            # the launch that produces dL/dfake (the first layer's input gradient) writes dL/dpre of the generator's
+            # output layer directly where it can (kernels.tconv_scatter(l1=)): the L1 + Tanh' pass over the image - 16 us
+            # on the critical path - then only has the loss VALUE left to compute, which it does on the second side stream
+            dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
+            fused_l1 = L1_FUSED and self.side2 is not None and Dn.l1_fused(self.ctx_r, 1)
+            dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1,     # dL/dfake only
+                             dx_l1=(fake, xb, G.out_nc, self.lambda_l1, dpre) if fused_l1 else None)
         finally:
             K.set_solo(self.side is None)
         if self._ev_d_free is not None and (not graph_safe or self._listing):
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
         self._mark("G phase: D forward + input gradient done")
-        dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
-        self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self._parts[192:], dpre)
+        if fused_l1:
+            K.wait_stream(self.side2, torch.cuda.current_stream())           # (orders the partials behind the previous step's readers)
+            with torch.cuda.stream(self.side2):
+                self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, None, 0, self.lambda_l1, self._parts[3 * PARTS:], None)
+        else:
+            self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self._parts[3 * PARTS:], dpre)
         garena = self.opt_g.flat().grad
         self._works = []
         hook = None
@@ -471,7 +483,10 @@ class GanTrainer:
         if bucketed:
             self._mark("side2: bucket updates done", self.side2)
         # loss_g of this step (here: the main stream would otherwise only wait for the side streams)
-        K.loss_finish(self._parts, [(128, 128 + self._nparts[2]), (192, 192 + self._nparts[3])], self.losses[1:2])
+        if fused_l1:
+            K.wait_stream(torch.cuda.current_stream(), self.side2)      # (the L1 partials were written there, long ago)
+        K.loss_finish(self._parts, [(2 * PARTS, 2 * PARTS + self._nparts[2]), (3 * PARTS, 3 * PARTS + self._nparts[3])],
+                      self.losses[1:2])
         if self.side is not None:
             K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:

@@ -205,6 +205,13 @@ int pfa_logit_supported(int dtype, int c, int ld, int h, int w);
 /* logits[.., 0] = bias[0] + sum_{tap,c} x[oy-1+ky][ox-1+kx][c] * w[tap][c]; channels 1..ld-1 are written as zeros. */
 int pfa_logit_fwd(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c, int ld,
                   pfa_stream s);
+/* pfa_logit_fwd with nn.BCEWithLogitsLoss (train_gan.py:42,58,60,67: mean reduction, constant target) in its epilogue -
+ * what pfa_bce_logits_parts computes from the stored logits, without the launch in between: dlogits[.., 0] = gscale *
+ * (sigmoid(x) - target) / count (pad channels zero), parts[workgroup] = lscale * (sum of the workgroup's loss terms) / count
+ * for pfa_loss_finish; pfa_logit_fwd_nparts(nb, h, wd) partials are written. */
+int pfa_logit_fwd_nparts(int nb, int h, int wd);
+int pfa_logit_fwd_bce(const void* x, const void* w, const float* bias, void* logits, int nb, int h, int wd, int c, int ld,
+                      float target, float lscale, float gscale, float* parts, void* dlogits, pfa_stream s);
 /* g[y][x][c] = sum_tap dlogits[y+1-ky][x+1-kx] * w[tap][c], then the backward of what feeds the layer, as
  * pfa_bn_bwd_reduce computes it: dy = act'(scale*raw + shift) * g (scale == NULL: identity map), and when mean != NULL
  * the partial sums of dy and dy*xhat -> part[2][pfa_logit_dgrad_tiles(nb,h,wd)][c] for pfa_bn_bwd_finalize. */
@@ -245,6 +252,17 @@ typedef struct pfa_scatter_args {
     const void* w;
     const float* bias;           /* [n] or NULL */
     void* out;
+    /* Optional fused epilogue of the generator phase (train_gan.py:66-70): the launch computes dL/dfake of the discriminator's
+     * first layer (this transposed form, no bias / activation), and with l1_fake != NULL `out` receives, instead of it,
+     * the gradient w.r.t. the generator's pre-Tanh output
+     *   dpre = (l1_scale * sign(fake - real) + bf16(dL/dfake)) * (1 - fake^2)     for channels < l1_creal, 0 beyond
+     * - what pfa_l1_tanh_bwd computes from the stored dL/dfake (same bits: the value is rounded to the storage type first).
+     * l1_fake / l1_real: [nb][2 hs][2 ws][ld], the output's geometry; l1_scale = lambda / (pixels * l1_creal).  The L1 loss
+     * value itself is not produced here (pfa_l1_tanh_bwd_parts with dpre == NULL, off the critical path). */
+    const void* l1_fake;
+    const void* l1_real;
+    float l1_scale;
+    int32_t l1_creal;
 } pfa_scatter_args;
 int pfa_tconv_scatter_supported(int dtype, int c1, int c2, int n, int ld);
 int pfa_tconv_scatter(const pfa_scatter_args* a, pfa_stream s);

@@ -39,7 +39,7 @@ def test_struct_layout_matches_the_header():
     # 18 int32/float fields then 9 pointers; 16 x 4 + 2 x 4 = 72 bytes of scalars, 8-byte aligned pointers after
     assert ctypes.sizeof(_lib.GatherArgs) == 72 + 9 * 8 + 16 + 6 * 8
     assert ctypes.sizeof(_lib.WgradArgs) == 18 * 4 + 6 * 8
-    assert ctypes.sizeof(_lib.ScatterArgs) == 12 * 4 + 5 * 8          # pfa_scatter_args
+    assert ctypes.sizeof(_lib.ScatterArgs) == 12 * 4 + 7 * 8 + 2 * 4   # pfa_scatter_args
 
 
 def test_asm_read_kernels_use_no_scratch():

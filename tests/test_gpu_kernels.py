@@ -598,6 +598,26 @@ def test_logit_layer_kernels(case, ws):
     assert _lib.launch_count() - before == 1
     close(from_nhwc(logits, 1), want, dtype, name + ".logits")
     assert float(logits[..., 1:].abs().max()) == 0.0                    # pad channels are written as zeros
+    # the same launch with BCEWithLogitsLoss in its epilogue (train_gan.py:58,60,67): logits, dlogits and - through
+    # pfa_loss_finish - the loss of the two-launch route (pfa_logit_fwd, pfa_bce_logits_parts): dlogits bit for bit
+    for target, ls, gs in ((1.0, 0.5, 0.5), (0.0, 1.0, 1.0)):
+        lg2 = torch.full_like(logits, 5.0)
+        dl_f = torch.full_like(logits, 5.0)
+        parts = torch.full((4096,), 3.0, device="cuda")
+        before = _lib.launch_count()
+        np_f = K.logit_fwd_bce(xd, same, torch.from_numpy(b).cuda(), lg2, target, ls, gs, parts, dl_f)
+        assert _lib.launch_count() - before == 1 and 0 < np_f <= 4096
+        assert torch.equal(lg2, logits)
+        dl_t = torch.full_like(logits, 9.0)
+        p2 = torch.zeros(64, device="cuda")
+        np_t = K.bce_logits_parts(logits, target, ls, gs, p2, dl_t)
+        assert torch.equal(dl_f, dl_t), "dlogits of the fused and the two-launch route differ"
+        o1, o2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        K.loss_finish(parts, [(0, np_f), (0, 0)], o1)
+        K.loss_finish(p2, [(0, np_t), (0, 0)], o2)
+        torch.cuda.synchronize()
+        lref, _ = ops.bce_logits(from_nhwc(logits, 1), target)
+        assert abs(float(o1[0]) - float(o2[0])) <= 2e-6 * abs(float(o2[0])) and abs(float(o1[0]) - ls * lref) <= 1e-5 * abs(ls * lref)
 
     # backward: dlogits -> (dw, db) and dy = LeakyReLU'(scale*raw + shift) * dx with the BatchNorm partial sums
     dl = rnd(fill.uniform(name + ".ldl", (n, 1, ho, wo), -1.0, 1.0), dtype)
@@ -705,6 +725,41 @@ def test_tconv_scatter(case, dtype, ws):
     ref = torch.full_like(out, 7.0)
     K.gather_gemm(K.TCONV_S2, srcs, tr, co, [ref], (n, h, w), ws, bias=bt, act=act)
     close(from_nhwc(out, co), from_nhwc(ref, co), dtype, name + " vs implicit GEMM")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("case", [("c1_dgrad", 2, 64, 13, 31, 3), ("ragged", 1, 64, 7, 33, 3), ("six", 2, 128, 6, 30, 6)],
+                         ids=lambda c: c[0])
+def test_tconv_scatter_fused_l1_tanh_epilogue(case, dtype, ws):
+    """The generator phase's fused epilogue (train_gan.py:66-70): the launch that computes dL/dfake of the discriminator's
+    first layer writes dL/dpre = (lambda sign(fake - real) / N + dL/dfake) (1 - fake^2) directly - bit for bit what the
+    two-launch route (pfa_tconv_scatter, then pfa_l1_tanh_bwd on the stored dL/dfake) produces, and the oracle's arithmetic."""
+    name, n, ci, h, w, co = case
+    x = rnd(fill.uniform(name + ".lx", (n, ci, h, w)), dtype)
+    wt = rnd(fill.uniform(name + ".lw", (ci, co, 4, 4), -0.25, 0.25), dtype)
+    fake = rnd(np.tanh(fill.uniform(name + ".lf", (n, co, 2 * h, 2 * w), -2, 2)), dtype)
+    real = rnd(fill.uniform(name + ".lr", (n, co, 2 * h, 2 * w)), dtype)
+    real[0, 0, 0, :3] = fake[0, 0, 0, :3]                       # sign(0) = 0
+    lam = 100.0
+    src = to_nhwc(x, dtype)
+    _, tr = shadows(wt, dtype, want=("tr",))
+    cp = K.pad_ch(co, dtype)
+    ft, rt = to_nhwc(fake, dtype), to_nhwc(real, dtype)
+    dx = torch.full((n, 2 * h, 2 * w, cp), 7.0, dtype=dtype, device="cuda")
+    K.tconv_scatter([src], tr, co, dx)
+    two = torch.full_like(dx, 5.0)
+    parts = torch.zeros(1024, device="cuda")
+    K.l1_tanh_bwd_parts(ft, rt, co, dx, 0, lam, parts, two)
+    one = torch.full_like(dx, 3.0)
+    K.tconv_scatter([src], tr, co, one, l1=(ft, rt, co, lam))
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), "fused epilogue and two-launch route differ"
+    dgan = rnd(ops.convT2d_fwd(x, wt, None), dtype)
+    d = fake.astype(np.float64) - real
+    want = (lam * np.sign(d) / d.size + dgan) * (1.0 - fake.astype(np.float64) ** 2)
+    close(from_nhwc(one, co), want, dtype, name)
+    with pytest.raises(_lib.PfaError, match="no bias"):
+        K.tconv_scatter([src], tr, co, one, act=K.ACT_TANH, l1=(ft, rt, co, lam))
 
 
 def test_tconv_scatter_support_and_errors():
