@@ -553,12 +553,8 @@ __global__ __launch_bounds__(256) void k_l1_tanh_bwd(const T* __restrict__ fake,
         for (int e = 0; e < CH; ++e) {
             float d = 0.f;
             if (c0 + e < c_real) {
-                const float df = f.v[e] - r.v[e];
-                local += fabsf(df);
-                const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                d = lambda * sgn * inv;
-                if (dgan) d += to_f32(dgan[pix * dgan_ld + dgan_off + c0 + e]);
-                d *= 1.f - f.v[e] * f.v[e];
+                local += fabsf(f.v[e] - r.v[e]);
+                d = l1_tanh_grad(f.v[e], r.v[e], dgan ? to_f32(dgan[pix * dgan_ld + dgan_off + c0 + e]) : 0.f, lambda, inv);
             }
             o.v[e] = d;
         }

@@ -134,6 +134,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 // derivative of the activation evaluated at its INPUT y (torch: x > 0 ? g : g*slope)
 __device__ __forceinline__ float act_grad(float y, int act, float slope) { return act_grad_lin(y, act_neg(act, slope)); }
 
+// d loss_g / d (pre-Tanh output) of one element (train_gan.py:67-69 through models.py:186): (lambda sign(fake - real) / N + dgan)
+// (1 - fake^2), every product and sum rounded on its own (no contraction) - two kernels form it (pfa_l1_tanh_bwd and the
+// fused epilogue of pfa_tconv_scatter) and must give the same bits.
+__device__ __forceinline__ float l1_tanh_grad(float f, float r, float dgan, float lambda, float inv) {
+    const float df = f - r;
+    const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+    const float d = __fadd_rn(__fmul_rn(__fmul_rn(lambda, sgn), inv), dgan);
+    return __fmul_rn(d, __fsub_rn(1.f, __fmul_rn(f, f)));
+}
+
 // XCD-aware work-item id (cdna guide T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs,
 // each with a private L2: give every XCD one CONTIGUOUS chunk of the work list so that workgroups which share an
 // operand tile hit the same L2.  Placement only changes speed, never results.

@@ -35,7 +35,7 @@ struct ScatterK {
     int kchunks, k1chunks;   // 128-byte K chunks in total / coming from src1
     const char* l1_fake;     // fused L1 + Tanh' epilogue (pfa_hip.h), or NULL
     const char* l1_real;
-    float l1_scale;
+    float l1_lambda;
     int l1_creal;
 };
 
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
     //      NCO == 8: column = tap*8 + co      -> tap = 2a + (kk >> 1),   co = 4*(kk&1) + r   (ky = a >> 1)
     // Output rows of one parity use two ky values; each pass writes that half of Y (fp32) and gathers from it.
     const int HO = 2 * p.hs, WO = 2 * p.ws;
+    const float l1_inv = 1.f / ((float)((int64_t)p.nb * HO * WO) * (float)p.l1_creal);      // (pfa_l1_tanh_bwd's 1 / (count * c_real))
     float bv[NCO];                       // bias of the real channels, fetched once (uniform addresses: scalar loads)
 #pragma unroll
     for (int e = 0; e < NCO; ++e) bv[e] = 0.f;
@@ -226,11 +227,9 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
                     const int c = e0 + e;
                     float t = 0.f;                           // pad lanes are exact zeros
                     if (c < NCO && c < p.n) t = apply_act(v[c < NCO ? c : 0] + bv[c < NCO ? c : 0], p.act, p.slope);
-                    if (p.l1_fake) {                         // dpre from dL/dfake as it would have been stored (pfa_l1_tanh_bwd)
-                        const float dgan = to_f32(from_f32<T>(t));
-                        const float df = f.v[e] - rl.v[e];
-                        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-                        t = c < p.l1_creal ? (p.l1_scale * sgn + dgan) * (1.f - f.v[e] * f.v[e]) : 0.f;
+                    if (p.l1_fake) {                         // dpre from dL/dfake as it would have been stored: the
+                        const float dgan = to_f32(from_f32<T>(t));     // (pfa_l1_tanh_bwd reads the stored value)
+                        t = c < p.l1_creal ? l1_tanh_grad(f.v[e], rl.v[e], dgan, p.l1_lambda, l1_inv) : 0.f;
                     }
                     o.v[e] = t;
                 }
@@ -286,7 +285,7 @@ extern "C" int pfa_tconv_scatter(const pfa_scatter_args* a, pfa_stream s) {
     PFA_REQUIRE((a->l1_fake == nullptr) == (a->l1_real == nullptr), "pfa_tconv_scatter: l1_fake and l1_real come together");
     PFA_REQUIRE(!a->l1_fake || (a->act == PFA_ACT_NONE && !a->bias && a->l1_creal > 0 && a->l1_creal <= a->n),
                 "pfa_tconv_scatter: the fused L1 epilogue takes a plain input-gradient launch (no bias / activation), 0 < l1_creal <= n");
-    k.l1_fake = (const char*)a->l1_fake; k.l1_real = (const char*)a->l1_real; k.l1_scale = a->l1_scale; k.l1_creal = a->l1_creal;
+    k.l1_fake = (const char*)a->l1_fake; k.l1_real = (const char*)a->l1_real; k.l1_lambda = a->l1_lambda; k.l1_creal = a->l1_creal;
     k.ty_tiles = (a->hs + PH - 3) / (PH - 2);
     k.tx_tiles = (a->ws + PW - 3) / (PW - 2);
     const int kch = 8 * pfa_ch(a->dtype);

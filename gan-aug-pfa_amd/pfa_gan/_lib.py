@@ -48,7 +48,7 @@ class ScatterArgs(Structure):
         ("c1", c_int32), ("c2", c_int32), ("n", c_int32), ("ld", c_int32), ("act", c_int32), ("slope", c_float),
         ("reserved", c_int32),
         ("src1", c_void_p), ("src2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
-        ("l1_fake", c_void_p), ("l1_real", c_void_p), ("l1_scale", c_float), ("l1_creal", c_int32),
+        ("l1_fake", c_void_p), ("l1_real", c_void_p), ("l1_lambda", c_float), ("l1_creal", c_int32),
     ]
 
 

@@ -304,9 +304,7 @@ def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE, l1=None):
         if fake.shape != out.shape or real.shape != out.shape:
             raise _lib.PfaError("tconv_scatter: the fused L1 epilogue needs fake / real of the output's shape")
         a.l1_fake, a.l1_real, a.l1_creal = ptr(fake), ptr(real), c_real
-        # lambda * (1 / (pixels * c_real)) in float32, the way pfa_l1_tanh_bwd forms it: the two routes give the same bits
-        f32 = __import__("numpy").float32
-        a.l1_scale = float(f32(lam) * (f32(1.0) / (f32(rows_of(out)) * f32(c_real))))
+        a.l1_lambda = float(lam)
     check(lib().pfa_tconv_scatter(ctypes.byref(a), stream()), "pfa_tconv_scatter")
 
 

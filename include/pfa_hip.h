@@ -255,13 +255,13 @@ typedef struct pfa_scatter_args {
     /* Optional fused epilogue of the generator phase (train_gan.py:66-70): the launch computes dL/dfake of the discriminator's
      * first layer (this transposed form, no bias / activation), and with l1_fake != NULL `out` receives, instead of it,
      * the gradient w.r.t. the generator's pre-Tanh output
-     *   dpre = (l1_scale * sign(fake - real) + bf16(dL/dfake)) * (1 - fake^2)     for channels < l1_creal, 0 beyond
+     *   dpre = (l1_lambda * sign(fake - real) / (pixels * l1_creal) + stored(dL/dfake)) * (1 - fake^2)   for channels < l1_creal, 0 beyond
      * - what pfa_l1_tanh_bwd computes from the stored dL/dfake (same bits: the value is rounded to the storage type first).
-     * l1_fake / l1_real: [nb][2 hs][2 ws][ld], the output's geometry; l1_scale = lambda / (pixels * l1_creal).  The L1 loss
+     * l1_fake / l1_real: [nb][2 hs][2 ws][ld], the output's geometry; l1_lambda = LAMBDA_L1 (train_gan.py:33).  The L1 loss
      * value itself is not produced here (pfa_l1_tanh_bwd_parts with dpre == NULL, off the critical path). */
     const void* l1_fake;
     const void* l1_real;
-    float l1_scale;
+    float l1_lambda;
     int32_t l1_creal;
 } pfa_scatter_args;
 int pfa_tconv_scatter_supported(int dtype, int c1, int c2, int n, int ld);
