@@ -361,6 +361,16 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
     const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
     const bool pub = blockIdx.x == 0;                   // this workgroup publishes its group's coefficients
     const bool fin = tid < cg;
+    // the first four row passes of this lane are fetched BEFORE the statistics are finished: their latency (the tensor was
+    // written by the previous kernel: a trip to memory) overlaps the partial sums' instead of following it
+    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
+    const size_t coff = (size_t)ch0 + (size_t)col * CH;
+    const int64_t stride = (int64_t)gridDim.x * rpp;
+    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
+    Chunk<T> pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (row + k * stride < rows) pre[k].load(raw + (size_t)(row + k * stride) * c + coff);
     if (pub && blockIdx.y == 0 && tid == 0 && nbt) *nbt += repeats;
     float g32 = 1.f, b32 = 0.f, rm32 = 0.f, rv32 = 0.f;    // fetched ahead of the reduction (see k_bn_finalize)
     if (fin) {
@@ -398,13 +408,9 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
         }
     }
     __syncthreads();
-    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
     float sc[CH], sf[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { sc[e] = cf[0][col * CH + e]; sf[e] = cf[1][col * CH + e]; }
-    const size_t coff = (size_t)ch0 + (size_t)col * CH;
-    const int64_t stride = (int64_t)gridDim.x * rpp;
-    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
     auto emit = [&](const Chunk<T>& x, int64_t r) {
         Chunk<T> l, rr;
 #pragma unroll
@@ -416,6 +422,10 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
         if (out_l) l.store(out_l + (size_t)r * c + coff);
         if (out_r) rr.store(out_r + (size_t)r * c + coff);
     };
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (row + k * stride < rows) emit(pre[k], row + k * stride);
+    row += 4 * stride;
     for (; row + 3 * stride < rows; row += 4 * stride) {     // four row passes in flight per lane
         Chunk<T> x0, x1, x2, x3;
         x0.load(raw + (size_t)row * c + coff);
@@ -441,6 +451,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
     __shared__ float cf[3][ST_CG];
     const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
     const bool pub = blockIdx.x == 0, fin = tid < cg;
+    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
+    const size_t coff = (size_t)ch0 + (size_t)col * CH;
+    const int64_t stride = (int64_t)gridDim.x * rpp;
+    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
+    Chunk<T> pd[2], px[2];                              // first two row passes fetched ahead of the statistics (see k_bn_act_stats)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (row + k * stride < rows) {
+            pd[k].load(dy + (size_t)(row + k * stride) * c + coff);
+            px[k].load(raw + (size_t)(row + k * stride) * c + coff);
+        }
     float g32 = 1.f, is32 = 0.f, mu32 = 0.f, dg32 = 0.f, db32 = 0.f;
     if (fin) {
         const int ch = ch0 + tid;
@@ -463,19 +484,19 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
         cf[2][tid] = (float)(-s * sdy / count + s * is * mu * sdyx / count);
     }
     __syncthreads();
-    const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
     float ka[CH], kb[CH], kc[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { ka[e] = cf[0][col * CH + e]; kb[e] = cf[1][col * CH + e]; kc[e] = cf[2][col * CH + e]; }
-    const size_t coff = (size_t)ch0 + (size_t)col * CH;
-    const int64_t stride = (int64_t)gridDim.x * rpp;
-    int64_t row = (int64_t)blockIdx.x * rpp + rsub;
     auto emit = [&](const Chunk<T>& d, const Chunk<T>& x, int64_t r) {
         Chunk<T> o;
 #pragma unroll
         for (int e = 0; e < CH; ++e) o.v[e] = ka[e] * d.v[e] + kb[e] * x.v[e] + kc[e];
         o.store(dr + (size_t)r * c + coff);
     };
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (row + k * stride < rows) emit(pd[k], px[k], row + k * stride);
+    row += 2 * stride;
     for (; row + stride < rows; row += 2 * stride) {
         Chunk<T> d0, x0, d1, x1;
         d0.load(dy + (size_t)row * c + coff);

@@ -138,10 +138,15 @@ __device__ __forceinline__ float act_grad(float y, int act, float slope) { retur
 // (1 - fake^2), every product and sum rounded on its own (no contraction) - two kernels form it (pfa_l1_tanh_bwd and the
 // fused epilogue of pfa_tconv_scatter) and must give the same bits.
 __device__ __forceinline__ float l1_tanh_grad(float f, float r, float dgan, float lambda, float inv) {
+#pragma clang fp contract(off)          // (HIP's __fmul_rn / __fadd_rn are plain operators: the compiler would still fuse them)
     const float df = f - r;
     const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-    const float d = __fadd_rn(__fmul_rn(__fmul_rn(lambda, sgn), inv), dgan);
-    return __fmul_rn(d, __fsub_rn(1.f, __fmul_rn(f, f)));
+    const float a = lambda * sgn;
+    const float b = a * inv;
+    const float d = b + dgan;
+    const float ff = f * f;
+    const float t = 1.f - ff;
+    return d * t;
 }
 
 // XCD-aware work-item id (cdna guide T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs,

@@ -739,7 +739,7 @@ class DiscriminatorEngine(_Engine):
             if L.bn is None:
                 out = ctx.buf(f"c{i}.a", shape, dt)
                 if self._logit_layer(i, a):
-                    if bce is not None and BCE_FUSED:
+                    if bce is not None and BCE_FUSED and K.logit_fwd_nparts(a[0]) <= bce[3].numel():
                         target, lscale, gscale, parts = bce
                         ctx.v["bce_nparts"] = K.logit_fwd_bce(a[0], L.same, L.b, out, target, lscale, gscale, parts,
                                                               ctx.buf("dlogits", shape, dt))

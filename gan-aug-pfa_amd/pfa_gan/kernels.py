@@ -398,6 +398,11 @@ def logit_fwd(x, w, bias, logits):
           "pfa_logit_fwd")
 
 
+def logit_fwd_nparts(x):
+    """Loss partials logit_fwd_bce writes for the input x [B,h,w,c] (one per workgroup)."""
+    return int(lib().pfa_logit_fwd_nparts(x.shape[0], x.shape[1], x.shape[2]))
+
+
 def logit_fwd_bce(x, w, bias, logits, target, lscale, gscale, parts, dlogits):
     """logit_fwd + bce_logits_parts in one launch.  -> number of partials written (parts[0 .. n))"""
     B, h, wd, c = x.shape

@@ -16,7 +16,7 @@ from ._lib import PfaError
 from .engine import FlatParams
 from .models import resolve_dtype
 
-PARTS = 1024           # loss partials per pass (GanTrainer._parts)
+PARTS = 4096           # loss partials per pass (GanTrainer._parts); a pass whose kernels would write more keeps the separate loss launch
 LAMBDA_L1 = 100.0      # train_gan.py:33
 LEARNING_RATE = 1e-4   # train_gan.py:28-29
 BETAS = (0.5, 0.999)   # train_gan.py:30,140-141
