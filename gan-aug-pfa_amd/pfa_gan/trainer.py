@@ -238,7 +238,9 @@ class GanTrainer:
         G, Dn = self.G, self.Dn
         parts = self._parts
         garena = self.opt_d.flat().grad
-        K.set_solo(self.side is None)         # one stream: every launch is alone on the GPU (see kernels.set_solo)
+        # one stream: every launch is alone on the GPU (see kernels.set_solo) - except in the tiny-batch hipGraph mode
+        # (use_graph="auto"), whose launches do not fill the chip either way: there the hint measured -0.7 %
+        K.set_solo(self._solo_default())
         if self.side is None:
             garena2 = self.opt_d.grad2()      # an arena per pass, as on three streams: a second pass ADDING to the first
             self.opt_d.zero_grad()            # one's sums would depend on the order of its float atomics
@@ -344,6 +346,9 @@ class GanTrainer:
         # loss_d of this step (before _ev_d_free: the next step's D(real) may overwrite its partials from there on)
         K.loss_finish(parts, [(0, self._nparts[0]), (PARTS, PARTS + self._nparts[1])], self.losses[0:1])
 
+    def _solo_default(self):
+        return self.side is None and not self._graph_one_stream
+
     def _d_forward_bce(self, srcs, ctx, slot, target, lscale, gscale):
         """Discriminator forward + BCE-with-logits (loss partials into slot `slot` of self._parts, dlogits into the context):
         one launch fewer where the logit layer's kernel carries the loss (DiscriminatorEngine.forward(bce=)).  -> dlogits"""
@@ -378,7 +383,7 @@ class GanTrainer:
             dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1,     # dL/dfake only
                              dx_l1=(fake, xb, G.out_nc, self.lambda_l1, dpre) if fused_l1 else None)
         finally:
-            K.set_solo(self.side is None)
+            K.set_solo(self._solo_default())
         if self._ev_d_free is not None and (not graph_safe or self._listing):
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
