@@ -379,7 +379,7 @@ class GanTrainer:
             # output layer directly where it can (kernels.tconv_scatter(l1=)): the L1 + Tanh' pass over the image - 16 us
             # on the critical path - then only has the loss VALUE left to compute, which it does on the second side stream
             dpre = self.gctx.buf("dpre", fake.shape, fake.dtype)
-            fused_l1 = L1_FUSED and self.side2 is not None and Dn.l1_fused(self.ctx_r, 1)
+            fused_l1 = L1_FUSED and Dn.l1_fused(self.ctx_r, 1)
             dx = Dn.backward(self.ctx_r, dl_g, None, param_grads=False, need_dx=True, dx_part=1,     # dL/dfake only
                              dx_l1=(fake, xb, G.out_nc, self.lambda_l1, dpre) if fused_l1 else None)
         finally:
@@ -388,10 +388,13 @@ class GanTrainer:
             K.record_event(self._ev_d_free, torch.cuda.current_stream())    # the next step's D(real) may start from here
             self._d_free_recorded = True
         self._mark("G phase: D forward + input gradient done")
-        if fused_l1:
+        l1_side = fused_l1 and self.side is not None          # (one stream - also the tiny-batch hipGraph mode: no fork)
+        if l1_side:
             K.wait_stream(self.side2, torch.cuda.current_stream())           # (orders the partials behind the previous step's readers)
             with torch.cuda.stream(self.side2):
                 self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, None, 0, self.lambda_l1, self._parts[3 * PARTS:], None)
+        elif fused_l1:
+            self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, None, 0, self.lambda_l1, self._parts[3 * PARTS:], None)
         else:
             self._nparts[3] = K.l1_tanh_bwd_parts(fake, xb, G.out_nc, dx, 0, self.lambda_l1, self._parts[3 * PARTS:], dpre)
         garena = self.opt_g.flat().grad
@@ -488,7 +491,7 @@ class GanTrainer:
         if bucketed:
             self._mark("side2: bucket updates done", self.side2)
         # loss_g of this step (here: the main stream would otherwise only wait for the side streams)
-        if fused_l1:
+        if l1_side:
             K.wait_stream(torch.cuda.current_stream(), self.side2)      # (the L1 partials were written there, long ago)
         K.loss_finish(self._parts, [(2 * PARTS, 2 * PARTS + self._nparts[2]), (3 * PARTS, 3 * PARTS + self._nparts[3])],
                       self.losses[1:2])
