@@ -347,6 +347,23 @@ __device__ __forceinline__ void group_tile_sums(const float* __restrict__ a, con
     }
 }
 
+// a 16-byte chunk kept packed (4 registers) while it is in flight; unpacked to floats when it is used
+template <typename T> struct Raw16;
+template <> struct Raw16<float> {
+    f32x4 q;
+    __device__ __forceinline__ void load(const float* p) { q = *(const f32x4*)p; }
+    __device__ __forceinline__ void unpack(Chunk<float>& c) const { c.v[0] = q[0]; c.v[1] = q[1]; c.v[2] = q[2]; c.v[3] = q[3]; }
+};
+template <> struct Raw16<bf16_t> {
+    bf16x8 q;
+    __device__ __forceinline__ void load(const bf16_t* p) { q = *(const bf16x8*)p; }
+    __device__ __forceinline__ void unpack(Chunk<bf16_t>& c) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c.v[i] = (float)q[i];
+    }
+};
+constexpr int ST_DEPTH = 8;            // row passes a lane keeps in flight (k_bn_act_stats; half of it, two tensors, backward)
+
 // grid (row blocks, channel groups).  Rows of a group are 16-byte chunks x cg/CH; a lane keeps one chunk column.
 template <typename T>
 __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw, int64_t rows, int c, int cg,
@@ -361,15 +378,15 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
     const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
     const bool pub = blockIdx.x == 0;                   // this workgroup publishes its group's coefficients
     const bool fin = tid < cg;
-    // the first four row passes of this lane are fetched BEFORE the statistics are finished: their latency (the tensor was
+    // the first ST_DEPTH row passes of this lane are fetched BEFORE the statistics are finished: their latency (the tensor was
     // written by the previous kernel: a trip to memory) overlaps the partial sums' instead of following it
     const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
     const size_t coff = (size_t)ch0 + (size_t)col * CH;
     const int64_t stride = (int64_t)gridDim.x * rpp;
     int64_t row = (int64_t)blockIdx.x * rpp + rsub;
-    Chunk<T> pre[4];
+    Raw16<T> pre[ST_DEPTH];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < ST_DEPTH; ++k)
         if (row + k * stride < rows) pre[k].load(raw + (size_t)(row + k * stride) * c + coff);
     if (pub && blockIdx.y == 0 && tid == 0 && nbt) *nbt += repeats;
     float g32 = 1.f, b32 = 0.f, rm32 = 0.f, rv32 = 0.f;    // fetched ahead of the reduction (see k_bn_finalize)
@@ -411,8 +428,9 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
     float sc[CH], sf[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { sc[e] = cf[0][col * CH + e]; sf[e] = cf[1][col * CH + e]; }
-    auto emit = [&](const Chunk<T>& x, int64_t r) {
-        Chunk<T> l, rr;
+    auto emit = [&](const Raw16<T>& xr, int64_t r) {
+        Chunk<T> x, l, rr;
+        xr.unpack(x);
 #pragma unroll
         for (int e = 0; e < CH; ++e) {
             const float y = x.v[e] * sc[e] + sf[e];
@@ -422,22 +440,17 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
         if (out_l) l.store(out_l + (size_t)r * c + coff);
         if (out_r) rr.store(out_r + (size_t)r * c + coff);
     };
+    // ST_DEPTH row passes in flight per lane: the grid is kept small (every workgroup re-reads the partial sums), so the
+    // bandwidth has to come from the depth of each lane's queue, not from the number of lanes
+    for (;;) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (row + k * stride < rows) emit(pre[k], row + k * stride);
-    row += 4 * stride;
-    for (; row + 3 * stride < rows; row += 4 * stride) {     // four row passes in flight per lane
-        Chunk<T> x0, x1, x2, x3;
-        x0.load(raw + (size_t)row * c + coff);
-        x1.load(raw + (size_t)(row + stride) * c + coff);
-        x2.load(raw + (size_t)(row + 2 * stride) * c + coff);
-        x3.load(raw + (size_t)(row + 3 * stride) * c + coff);
-        emit(x0, row); emit(x1, row + stride); emit(x2, row + 2 * stride); emit(x3, row + 3 * stride);
-    }
-    for (; row < rows; row += stride) {
-        Chunk<T> x;
-        x.load(raw + (size_t)row * c + coff);
-        emit(x, row);
+        for (int k = 0; k < ST_DEPTH; ++k)
+            if (row + k * stride < rows) emit(pre[k], row + k * stride);
+        row += ST_DEPTH * stride;
+        if (row >= rows) break;
+#pragma unroll
+        for (int k = 0; k < ST_DEPTH; ++k)
+            if (row + k * stride < rows) pre[k].load(raw + (size_t)(row + k * stride) * c + coff);
     }
 }
 
@@ -455,9 +468,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
     const size_t coff = (size_t)ch0 + (size_t)col * CH;
     const int64_t stride = (int64_t)gridDim.x * rpp;
     int64_t row = (int64_t)blockIdx.x * rpp + rsub;
-    Chunk<T> pd[2], px[2];                              // first two row passes fetched ahead of the statistics (see k_bn_act_stats)
+    constexpr int DEPTH = ST_DEPTH / 2;
+    Raw16<T> pd[DEPTH], px[DEPTH];                      // first row passes fetched ahead of the statistics (see k_bn_act_stats)
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < DEPTH; ++k)
         if (row + k * stride < rows) {
             pd[k].load(dy + (size_t)(row + k * stride) * c + coff);
             px[k].load(raw + (size_t)(row + k * stride) * c + coff);
@@ -487,29 +501,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
     float ka[CH], kb[CH], kc[CH];
 #pragma unroll
     for (int e = 0; e < CH; ++e) { ka[e] = cf[0][col * CH + e]; kb[e] = cf[1][col * CH + e]; kc[e] = cf[2][col * CH + e]; }
-    auto emit = [&](const Chunk<T>& d, const Chunk<T>& x, int64_t r) {
-        Chunk<T> o;
+    auto emit = [&](const Raw16<T>& dr16, const Raw16<T>& xr16, int64_t r) {
+        Chunk<T> d, x, o;
+        dr16.unpack(d);
+        xr16.unpack(x);
 #pragma unroll
         for (int e = 0; e < CH; ++e) o.v[e] = ka[e] * d.v[e] + kb[e] * x.v[e] + kc[e];
         o.store(dr + (size_t)r * c + coff);
     };
+    for (;;) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (row + k * stride < rows) emit(pd[k], px[k], row + k * stride);
-    row += 2 * stride;
-    for (; row + stride < rows; row += 2 * stride) {
-        Chunk<T> d0, x0, d1, x1;
-        d0.load(dy + (size_t)row * c + coff);
-        x0.load(raw + (size_t)row * c + coff);
-        d1.load(dy + (size_t)(row + stride) * c + coff);
-        x1.load(raw + (size_t)(row + stride) * c + coff);
-        emit(d0, x0, row); emit(d1, x1, row + stride);
-    }
-    for (; row < rows; row += stride) {
-        Chunk<T> d, x;
-        d.load(dy + (size_t)row * c + coff);
-        x.load(raw + (size_t)row * c + coff);
-        emit(d, x, row);
+        for (int k = 0; k < DEPTH; ++k)
+            if (row + k * stride < rows) emit(pd[k], px[k], row + k * stride);
+        row += DEPTH * stride;
+        if (row >= rows) break;
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k)
+            if (row + k * stride < rows) {
+                pd[k].load(dy + (size_t)(row + k * stride) * c + coff);
+                px[k].load(raw + (size_t)(row + k * stride) * c + coff);
+            }
     }
 }
 
@@ -898,7 +909,7 @@ static dim3 stats_grid(int64_t rows, int c, int cg, int dtype, int ntiles) {
     int64_t cap = ((int64_t)64 << 20) / ((int64_t)ntiles * cg * 8);
     if (cap > 2048) cap = 2048;
     int64_t gx = cap / groups;
-    if (gx > (passes + 3) / 4) gx = (passes + 3) / 4;       // ~4 row passes per lane
+    if (gx > (passes + 3) / 4) gx = (passes + 3) / 4;       // at least ~4 row passes per lane
     if (gx < 1) gx = 1;
     return dim3((unsigned)gx, (unsigned)groups);
 }
