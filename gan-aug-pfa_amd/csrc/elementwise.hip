@@ -304,11 +304,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* dy, const T* __re
 constexpr int ST_LANES = 16, ST_CG = 64, ST_UNROLL = 8;
 
 // -> sums of a[tile][ch] and b[tile][ch] over the tiles for the cg channels from ch0, left in sh[0][0][.] / sh[1][0][.]
+// `prefetch` is called once, right behind the issue of the FIRST round of partial-sum loads: vector-memory results come back
+// in issue order, so bulk loads issued in front of the partials would put their whole latency in front of the statistics.
+template <typename F>
 __device__ __forceinline__ void group_tile_sums(const float* __restrict__ a, const float* __restrict__ b, int ntiles, int c,
-                                                int ch0, int cg, double (*sh)[ST_LANES][ST_CG]) {
+                                                int ch0, int cg, double (*sh)[ST_LANES][ST_CG], F prefetch) {
     const int quads = cg >> 2, tid = threadIdx.x;
     const int quad = tid % quads, tl = tid / quads;
     const bool active = tl < ST_LANES;
+    bool fetched = false;
     if (active) {
         double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
         const float* pa = a + ch0 + 4 * quad;
@@ -326,6 +330,7 @@ __device__ __forceinline__ void group_tile_sums(const float* __restrict__ a, con
                     bv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            if (!fetched) { prefetch(); fetched = true; }
 #pragma unroll
             for (int u = 0; u < ST_UNROLL; ++u)
 #pragma unroll
@@ -334,6 +339,7 @@ __device__ __forceinline__ void group_tile_sums(const float* __restrict__ a, con
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sh[0][tl][4 * quad + e] = s[e]; sh[1][tl][4 * quad + e] = q[e]; }
     }
+    if (!fetched) prefetch();                               // (lanes without a share of the partial sums)
     __syncthreads();
     for (int off = ST_LANES / 2; off > 0; off >>= 1) {
         if (active && tl < off) {
@@ -378,16 +384,19 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
     const int tid = threadIdx.x, ch0 = blockIdx.y * cg;
     const bool pub = blockIdx.x == 0;                   // this workgroup publishes its group's coefficients
     const bool fin = tid < cg;
-    // the first ST_DEPTH row passes of this lane are fetched BEFORE the statistics are finished: their latency (the tensor was
-    // written by the previous kernel: a trip to memory) overlaps the partial sums' instead of following it
+    // the first ST_DEPTH row passes of this lane are fetched while the statistics are being finished (issued right behind the
+    // first round of partial-sum loads): their latency - the tensor was written by the previous kernel: a trip to memory -
+    // overlaps the reduction instead of following it
     const int cprg = cg / CH, col = tid % cprg, rsub = tid / cprg, rpp = 256 / cprg;
     const size_t coff = (size_t)ch0 + (size_t)col * CH;
     const int64_t stride = (int64_t)gridDim.x * rpp;
     int64_t row = (int64_t)blockIdx.x * rpp + rsub;
     Raw16<T> pre[ST_DEPTH];
+    auto prefetch = [&]() {
 #pragma unroll
-    for (int k = 0; k < ST_DEPTH; ++k)
-        if (row + k * stride < rows) pre[k].load(raw + (size_t)(row + k * stride) * c + coff);
+        for (int k = 0; k < ST_DEPTH; ++k)
+            if (row + k * stride < rows) pre[k].load(raw + (size_t)(row + k * stride) * c + coff);
+    };
     if (pub && blockIdx.y == 0 && tid == 0 && nbt) *nbt += repeats;
     float g32 = 1.f, b32 = 0.f, rm32 = 0.f, rv32 = 0.f;    // fetched ahead of the reduction (see k_bn_finalize)
     if (fin) {
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
         if (beta) b32 = beta[ch0 + tid];
         if (pub && running_mean) { rm32 = running_mean[ch0 + tid]; rv32 = running_var[ch0 + tid]; }
     }
-    group_tile_sums(psum, psq, ntiles, c, ch0, cg, sh);
+    group_tile_sums(psum, psq, ntiles, c, ch0, cg, sh, prefetch);
     if (fin) {
         const double s = sh[0][0][tid], q = sh[1][0][tid];
         const double mean = s / count;
@@ -469,13 +478,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
     const int64_t stride = (int64_t)gridDim.x * rpp;
     int64_t row = (int64_t)blockIdx.x * rpp + rsub;
     constexpr int DEPTH = ST_DEPTH / 2;
-    Raw16<T> pd[DEPTH], px[DEPTH];                      // first row passes fetched ahead of the statistics (see k_bn_act_stats)
+    Raw16<T> pd[DEPTH], px[DEPTH];                      // first row passes fetched under the statistics (see k_bn_act_stats)
+    auto prefetch = [&]() {
 #pragma unroll
-    for (int k = 0; k < DEPTH; ++k)
-        if (row + k * stride < rows) {
-            pd[k].load(dy + (size_t)(row + k * stride) * c + coff);
-            px[k].load(raw + (size_t)(row + k * stride) * c + coff);
-        }
+        for (int k = 0; k < DEPTH; ++k)
+            if (row + k * stride < rows) {
+                pd[k].load(dy + (size_t)(row + k * stride) * c + coff);
+                px[k].load(raw + (size_t)(row + k * stride) * c + coff);
+            }
+    };
     float g32 = 1.f, is32 = 0.f, mu32 = 0.f, dg32 = 0.f, db32 = 0.f;
     if (fin) {
         const int ch = ch0 + tid;
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply_stats(const T* dy, const T
         if (pub && dgamma) dg32 = dgamma[ch];
         if (pub && dbeta) db32 = dbeta[ch];
     }
-    group_tile_sums(part, part + (size_t)ntiles * c, ntiles, c, ch0, cg, sh);
+    group_tile_sums(part, part + (size_t)ntiles * c, ntiles, c, ch0, cg, sh, prefetch);
     if (fin) {
         const double sdy = sh[0][0][tid], sdyx = sh[1][0][tid];
         if (pub) {

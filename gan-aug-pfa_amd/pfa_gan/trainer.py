@@ -32,7 +32,9 @@ BUCKET_UPDATE = _os.environ.get("PFA_BUCKET_UPDATE", "1") != "0"     # Adam + sh
 BUCKET_UPDATE_D = _os.environ.get("PFA_BUCKET_UPDATE_D", "0") != "0"   # one GPU: Adam(D) bucket by bucket under the D phase: measured -0.7 % (its range update queues in front of D(fake)'s remaining weight gradients on side2): off
 EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the generator's gradient arena under the D phase (A/B switch)
 DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"   # measured -2.0 %: off (see GanTrainer._d_update_g_phase)
-L1_FUSED = _os.environ.get("PFA_L1_FUSED", "1") != "0"               # dL/dpre from the launch that computes dL/dfake (A/B switch)
+# dL/dpre from the launch that computes dL/dfake: measured -0.2 % at 256x256 and -0.9 % at 512x512 (the loss-only L1 pass on
+# the side stream collides with the HBM-bound first launches of the generator backward): off
+L1_FUSED = _os.environ.get("PFA_L1_FUSED", "0") != "0"
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
