@@ -351,7 +351,8 @@ class _Engine:
         coefficients + running buffers + normalise / activate.  One launch (every workgroup finishes the statistics of
         its own channel group in its prologue) where the shape allows it, else bn_finalize + bn_act."""
         psum, psq, nt = st
-        if not K.bn_stats_fused_ok(raw.dtype, L.cout, nt) or raw.shape[3] != L.cout:
+        traffic = raw.numel() * raw.element_size() * (1 + (out_l is not None) + (out_r is not None))
+        if not K.bn_stats_fused_ok(raw.dtype, L.cout, nt, traffic) or raw.shape[3] != L.cout:
             scale, shift = self._bn_coeffs(L, ctx, tag, st, count, True, repeats)
             K.bn_act(raw, scale, shift, out_l, out_r)
             return
@@ -418,7 +419,7 @@ class _Engine:
         mean, invstd = ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32)
         dgamma = self.flat.seg(garena, L.bn.weight) if param_grads else None
         dbeta = self.flat.seg(garena, L.bn.bias) if param_grads else None
-        if K.bn_stats_fused_ok(raw.dtype, c, nt) and raw.shape[3] == c:
+        if K.bn_stats_fused_ok(raw.dtype, c, nt, 3 * raw.numel() * raw.element_size()) and raw.shape[3] == c:
             K.bn_bwd_apply_stats(dy, raw, part, nt, count, L.bn.weight, mean, invstd, dgamma, dbeta, dy)
             return dy
         coef = ctx.buf(tag + ".coef", (3 * c,), f32)

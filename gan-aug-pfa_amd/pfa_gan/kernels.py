@@ -457,9 +457,18 @@ def bn_act(raw, scale, shift, out_l=None, out_r=None):
                            ptr(out_l), ptr(out_r), stream()), "pfa_bn_act")
 
 
-def bn_stats_fused_ok(dtype, c, ntiles):
-    """Can the coefficient launch be folded into the pass that applies it (bn_act_stats / bn_bwd_apply_stats)?"""
-    return BN_STATS_FUSED and bool(lib().pfa_bn_stats_fused_supported(dt_code(dtype), c, ntiles))
+# Bytes a folded pass may move (read + written).  Every workgroup of the folded form re-reads its channels' partial sums, so its
+# grid stays small and the bandwidth comes from each lane's queue depth: up to ~50 MB (the 16.8 MB tensors of B = 16 at 256 x
+# 256 with two outputs) it is as fast as or faster than the two launches, on the 100 MB passes of 512 x 512 the two launches
+# with their 2048-workgroup apply win (same-box A/B: 512 x 512 step +0.4 % without the folded form, 256 x 256 -0.5 %).
+BN_STATS_MAX_BYTES = int(_os.environ.get("PFA_BN_STATS_MAX_MB", "64")) << 20
+
+
+def bn_stats_fused_ok(dtype, c, ntiles, traffic=0):
+    """Should the coefficient launch be folded into the pass that applies it (bn_act_stats / bn_bwd_apply_stats)?
+    traffic: bytes the pass reads + writes (0 = unknown: shape support only)."""
+    return (BN_STATS_FUSED and traffic <= BN_STATS_MAX_BYTES
+            and bool(lib().pfa_bn_stats_fused_supported(dt_code(dtype), c, ntiles)))
 
 
 def bn_act_stats(raw, psum, psq, ntiles, count, gamma, beta, running_mean, running_var, nbt, scale, shift, mean, invstd,
