@@ -161,7 +161,11 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     per = _timed_kernels(lib, _lib)
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     unit = FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0]
-    return _roofline_object(per, steps, peak, unit, f"train_b{xa.shape[0]}_{xa.shape[1]}_{precision}")
+    roof = _roofline_object(per, steps, peak, unit, f"train_b{xa.shape[0]}_{xa.shape[1]}_{precision}")
+    roof["mode"] = ("one HIP stream: every launch alone on the GPU (launch plans for a GPU of its own: the stride-1 input "
+                    "gradients K-sliced); in the timed three-stream step the launches that share the GPU with other streams "
+                    "take the plans tuned for sharing (e.g. two of c4's three input gradients un-sliced, no partial planes)")
+    return roof
 
 
 # ----------------------------------------------------------------------------------------------------- CPU baseline
