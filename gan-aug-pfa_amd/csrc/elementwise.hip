@@ -678,15 +678,35 @@ __global__ __launch_bounds__(256) void k_colsum_final(const float* __restrict__ 
 // ------------------------------------------------------------------ Adam
 __global__ void k_adam_tick(int32_t* step) { *step += 1; }
 
+// optim.Adam(lr, betas) of one element (torch: step_size = lr / (1 - b1^t); denom = sqrt(v) / sqrt(1 - b2^t) + eps).  Three
+// kernels apply it (k_adam, k_adam_shadow, k_adam_gaps) and must give the same bits: no contraction.
+struct AdamK { float b1, b2, eps, step_size, bc2s, grad_scale; };
+__device__ __forceinline__ AdamK adam_consts(float lr, float b1, float b2, float eps, int step, const int32_t* step_dev,
+                                             float grad_scale) {
+    const int t = step_dev ? *step_dev : step;
+    const float bc1 = 1.f - powf(b1, (float)t);
+    return AdamK{b1, b2, eps, lr / bc1, sqrtf(1.f - powf(b2, (float)t)), grad_scale};
+}
+__device__ __forceinline__ void adam_update(const AdamK& k, float& p, float g, float& m, float& v) {
+#pragma clang fp contract(off)
+    const float ge = g * k.grad_scale;
+    const float m1 = k.b1 * m;
+    const float m2 = (1.f - k.b1) * ge;
+    m = m1 + m2;
+    const float v1 = k.b2 * v;
+    const float v2 = (1.f - k.b2) * ge;
+    const float v3 = v2 * ge;
+    v = v1 + v3;
+    const float den = sqrtf(v) / k.bc2s + k.eps;
+    const float upd = k.step_size * (m / den);
+    p = p - upd;
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                               const float* __restrict__ g2, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float lr, float b1, float b2,
                                               float eps, int step, const int32_t* step_dev, float grad_scale, int nt) {
-    const int t = step_dev ? *step_dev : step;
-    // torch: step_size = lr/(1-b1^t); denom = sqrt(v)/sqrt(1-b2^t) + eps
-    const float bc1 = 1.f - powf(b1, (float)t);
-    const float bc2s = sqrtf(1.f - powf(b2, (float)t));
-    const float step_size = lr / bc1;
+    const AdamK k = adam_consts(lr, b1, b2, eps, step, step_dev, grad_scale);
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         // m and v are touched once per step and nowhere else: non-temporal, so that 650 MB of moments do not sweep the
@@ -699,10 +719,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         if (g2) gg += ((const f32x4*)g2)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float ge = gg[e] * grad_scale;
-            mm[e] = b1 * mm[e] + (1.f - b1) * ge;
-            vv[e] = b2 * vv[e] + (1.f - b2) * ge * ge;
-            pp[e] -= step_size * (mm[e] / (sqrtf(vv[e]) / bc2s + eps));
+            float pe = pp[e], me = mm[e], ve = vv[e];
+            adam_update(k, pe, gg[e], me, ve);
+            pp[e] = pe; mm[e] = me; vv[e] = ve;
         }
         ((f32x4*)p)[i] = pp;
         if (nt) { __builtin_nontemporal_store(mm, (f32x4*)m + i); __builtin_nontemporal_store(vv, (f32x4*)v + i); }
@@ -710,11 +729,25 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
-        const float ge = (g[i] + (g2 ? g2[i] : 0.f)) * grad_scale;
-        const float me = b1 * m[i] + (1.f - b1) * ge;
-        const float ve = b2 * v[i] + (1.f - b2) * ge * ge;
-        m[i] = me; v[i] = ve;
-        p[i] -= step_size * (me / (sqrtf(ve) / bc2s + eps));
+        float pe = p[i], me = m[i], ve = v[i];
+        adam_update(k, pe, g[i] + (g2 ? g2[i] : 0.f), me, ve);
+        p[i] = pe; m[i] = me; v[i] = ve;
+    }
+}
+
+// Adam on the arena ranges that are NOT convolution weights (BatchNorm gamma / beta, biases: the gaps between the layers a
+// k_adam_shadow launch covers): one workgroup per range, tab[i] = {first element, length}.
+__global__ __launch_bounds__(256) void k_adam_gaps(const int64_t* __restrict__ tab, float* __restrict__ p,
+                                                   const float* __restrict__ g, const float* __restrict__ g2,
+                                                   float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2,
+                                                   float eps, int step, const int32_t* step_dev, float grad_scale) {
+    const AdamK k = adam_consts(lr, b1, b2, eps, step, step_dev, grad_scale);
+    const int64_t o = tab[2 * blockIdx.x], n = tab[2 * blockIdx.x + 1];
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+        const int64_t i = o + j;
+        float pe = p[i], me = m[i], ve = v[i];
+        adam_update(k, pe, g[i] + (g2 ? g2[i] : 0.f), me, ve);
+        p[i] = pe; m[i] = me; v[i] = ve;
     }
 }
 
@@ -790,9 +823,16 @@ __global__ __launch_bounds__(256) void k_unpack_nchw(const T* __restrict__ src, 
 // fp32 master once (256-byte coalesced rows), keeps it in LDS and writes `same` (rows of 64 channels) and `tr` (rows of 64
 // master-rows) with 16-byte stores.  The layer of a block is found by one ballot over the descriptor table (a serial scan
 // costs a load latency per layer and block).  335 MB instead of 502 MB for the generator, no per-element div/mod.
+// ADAM: the same launch first applies optim.Adam to the master elements of its tile (p, g [+ g2], m, v of the flat arenas:
+// a weight's elements sit at the same offsets in all of them) - one pass over the parameters instead of k_adam followed by a
+// re-read of the master for the copies.
+struct AdamArenas {
+    float* p; const float* g; const float* g2; float* m; float* v;
+    float lr, b1, b2, eps, grad_scale; int step; const int32_t* step_dev;
+};
 constexpr int SH_TILE = 64;
-template <typename T>
-__global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_desc* __restrict__ descs, int n) {
+template <typename T, bool ADAM>
+__global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_desc* __restrict__ descs, int n, const AdamArenas A) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int GROUPS = SH_TILE / CH;                  // 16-byte groups per tile row
     __shared__ float tile[SH_TILE][SH_TILE + 1];
@@ -810,10 +850,30 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
         const int tx = tid & 63, ty = tid >> 6;
         const int cp = cp0 + tx;
         const int c = cp < cp_tot ? real_channel(cp, d.c1r, d.c1p, d.c2r) : -1;
+        if (!ADAM) {
 #pragma unroll
-        for (int k = 0; k < SH_TILE / 4; ++k) {
-            const int r = r0 + ty + 4 * k;
-            tile[ty + 4 * k][tx] = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
+            for (int k = 0; k < SH_TILE / 4; ++k) {
+                const int r = r0 + ty + 4 * k;
+                tile[ty + 4 * k][tx] = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
+            }
+        } else {
+            const AdamK ak = adam_consts(A.lr, A.b1, A.b2, A.eps, A.step, A.step_dev, A.grad_scale);
+            const size_t base = (size_t)(d.master - A.p);           // the weight's first element in the arenas
+#pragma unroll 4
+            for (int k = 0; k < SH_TILE / 4; ++k) {
+                const int r = r0 + ty + 4 * k;
+                float pe = 0.f;
+                if (c >= 0 && r < d.rows) {
+                    const size_t i = base + ((size_t)r * 16 + tap) * cr + c;
+                    pe = A.p[i];
+                    float me = __builtin_nontemporal_load(A.m + i), ve = __builtin_nontemporal_load(A.v + i);
+                    adam_update(ak, pe, A.g[i] + (A.g2 ? A.g2[i] : 0.f), me, ve);
+                    A.p[i] = pe;
+                    __builtin_nontemporal_store(me, A.m + i);
+                    __builtin_nontemporal_store(ve, A.v + i);
+                }
+                tile[ty + 4 * k][tx] = pe;
+            }
         }
     }
     __syncthreads();
@@ -1187,9 +1247,31 @@ extern "C" int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, 
     PFA_REQUIRE(descs_dev && n > 0 && n <= 64 && tr_blocks > 0, "pfa_weight_shadow_batch: bad arguments (at most 64 layers per table)");
     (void)same_blocks;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(k_shadow_fused_batch<bf16_t>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n),
-               hipLaunchKernelGGL(k_shadow_fused_batch<float>, dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n));
+               hipLaunchKernelGGL((k_shadow_fused_batch<bf16_t, false>), dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n, AdamArenas{}),
+               hipLaunchKernelGGL((k_shadow_fused_batch<float, false>), dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n, AdamArenas{}));
     PFA_LAUNCHED("k_shadow_fused_batch");
+    return 0;
+}
+
+extern "C" int pfa_adam_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int tr_blocks, int dtype, const int64_t* gaps_dev,
+                                     int ngaps, float* p, const float* g, const float* g2, float* m, float* v, float lr,
+                                     float beta1, float beta2, float eps, int step, const int32_t* step_dev, float grad_scale,
+                                     pfa_stream s) {
+    PFA_REQUIRE(p && g && m && v && (n == 0 || (descs_dev && n > 0 && n <= 64 && tr_blocks > 0)) && (ngaps == 0 || gaps_dev) &&
+                (n > 0 || ngaps > 0), "pfa_adam_shadow_batch: bad arguments (at most 64 layers per table)");
+    PFA_REQUIRE(step_dev || step >= 1, "pfa_adam_shadow_batch: step must be >= 1");
+    const AdamArenas A{p, g, g2, m, v, lr, beta1, beta2, eps, grad_scale, step, step_dev};
+    if (n > 0) {
+        DISPATCH_T(dtype,
+                   hipLaunchKernelGGL((k_shadow_fused_batch<bf16_t, true>), dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n, A),
+                   hipLaunchKernelGGL((k_shadow_fused_batch<float, true>), dim3(tr_blocks), dim3(256), 0, (hipStream_t)s, descs_dev, n, A));
+        PFA_LAUNCHED("k_adam_shadow");
+    }
+    if (ngaps > 0) {
+        hipLaunchKernelGGL(k_adam_gaps, dim3(ngaps), dim3(256), 0, (hipStream_t)s, gaps_dev, p, g, g2, m, v, lr, beta1, beta2, eps,
+                           step, step_dev, grad_scale);
+        PFA_LAUNCHED("k_adam_gaps");
+    }
     return 0;
 }
 

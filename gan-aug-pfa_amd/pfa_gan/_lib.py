@@ -124,6 +124,8 @@ PROTOTYPES = {
     "pfa_weight_shadow": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pfa_shadow_blocks": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "pfa_weight_shadow_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "pfa_adam_shadow_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_float, c_float, c_float, c_float, c_int, c_void_p, c_float, c_void_p]),
     "pfa_pack_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_unpack_nchw": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pfa_unpack_u8": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p]),

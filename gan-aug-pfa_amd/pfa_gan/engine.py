@@ -292,6 +292,46 @@ class _Engine:
             K.check(K.lib().pfa_weight_shadow_batch(tab.data_ptr(), n, sb, tb, K.dt_code(self.dtype), K.stream()),
                     "pfa_weight_shadow_batch")
 
+    def _gap_table(self, lo, hi):
+        """Device table of the arena ranges in [lo, hi) that are not convolution weights (BatchNorm gamma / beta, biases),
+        adjacent ones merged: int64 pairs {first element, length}.  -> (tensor or None, number of ranges)"""
+        conv = {id(L.w) for L in self.layers}
+        gaps = []
+        for p in self.flat.params:
+            o, n = self.flat.slots[id(p)]
+            if id(p) in conv or not (lo <= o < hi):
+                continue
+            if gaps and gaps[-1][0] + gaps[-1][1] == o:
+                gaps[-1][1] += n
+            else:
+                gaps.append([o, n])
+        if not gaps:
+            return None, 0
+        return torch.tensor(gaps, dtype=torch.int64).to(self.device), len(gaps)
+
+    def adam_refresh_range(self, opt, lo, hi, grad_scale=1.0, use_grad2=False):
+        """FusedAdam.step_range(lo, hi) + refresh_shadows_range(lo, hi) in one pass over the parameters
+        (pfa_adam_shadow_batch): the launch that emits the kernel-side copies of the range's layers applies Adam to their
+        master elements first; the range's other parameters (BatchNorm, biases) take a small launch of their own.  The step
+        count is opt's (step_begin() / the device counter), as in step_range."""
+        tabs = self.__dict__.setdefault("_adam_tables", {})
+        if (lo, hi) not in tabs:
+            sub = [L for L in self.layers if lo <= self.flat.slots[id(L.w)][0] < hi]
+            tabs[(lo, hi)] = (self._shadow_table(sub) if sub else None, self._gap_table(lo, hi))
+        shadow, (gaps, ngaps) = tabs[(lo, hi)]
+        tab, n, _, tb = shadow if shadow is not None else (None, 0, 0, 0)
+        flat = opt.flat()
+        if flat is not self.flat:
+            raise PfaError("adam_refresh_range: the optimizer belongs to another module")
+        g = opt.param_groups[0]
+        dev_step = getattr(opt, "_range_dev", False)
+        K.check(K.lib().pfa_adam_shadow_batch(K.ptr(tab), n, tb, K.dt_code(self.dtype), K.ptr(gaps), ngaps,
+                                              flat.data.data_ptr(), flat.grad.data_ptr(),
+                                              opt.grad2().data_ptr() if use_grad2 else None, opt.m.data_ptr(), opt.v.data_ptr(),
+                                              g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0 if dev_step else opt.steps,
+                                              opt.step_dev.data_ptr() if dev_step else None, float(grad_scale), K.stream()),
+                "pfa_adam_shadow_batch")
+
     def shadows_refreshed(self):
         """All ranges have been re-emitted for the current parameters (bookkeeping of refresh_shadows)."""
         self.bn_epoch += 1

@@ -35,6 +35,7 @@ DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"  
 # dL/dpre from the launch that computes dL/dfake: measured -0.2 % at 256x256 and -0.9 % at 512x512 (the loss-only L1 pass on
 # the side stream collides with the HBM-bound first launches of the generator backward): off
 L1_FUSED = _os.environ.get("PFA_L1_FUSED", "0") != "0"
+ADAM_SHADOW_FUSED = _os.environ.get("PFA_ADAM_SHADOW_FUSED", "1") != "0"   # Adam + weight copies in one pass (A/B switch)
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
@@ -365,6 +366,11 @@ class GanTrainer:
         G, Dn = self.G, self.Dn
         if getattr(self, "_d_updated", False):        # already updated bucket by bucket during the D phase
             self._d_updated = False
+        elif ADAM_SHADOW_FUSED:
+            # Adam and the kernel-side weight copies in one pass over the parameters (pfa_adam_shadow_batch)
+            self.opt_d.step_begin(graph_safe)
+            Dn.adam_refresh_range(self.opt_d, 0, self.opt_d.flat().total, grad_scale=1.0 / self.world, use_grad2=True)
+            Dn.shadows_refreshed()
         else:
             self.opt_d.step(grad_scale=1.0 / self.world, graph_safe=graph_safe, use_grad2=True)
             Dn.refresh_shadows(force=True)
@@ -430,8 +436,11 @@ class GanTrainer:
                     else:
                         merged.append([lo, hi])
                 for lo, hi in merged:
-                    self.opt_g.step_range(lo, hi, grad_scale=scale)
-                    G.refresh_shadows_range(lo, hi)
+                    if ADAM_SHADOW_FUSED:
+                        G.adam_refresh_range(self.opt_g, lo, hi, grad_scale=scale)
+                    else:
+                        self.opt_g.step_range(lo, hi, grad_scale=scale)
+                        G.refresh_shadows_range(lo, hi)
 
             def hook(i):
                 lo, hi = buckets[i]
@@ -511,6 +520,10 @@ class GanTrainer:
     def _g_update(self, graph_safe):
         if getattr(self, "_g_updated", False):       # already updated bucket by bucket during the backward
             self._g_updated = False
+        elif ADAM_SHADOW_FUSED:
+            self.opt_g.step_begin(graph_safe)
+            self.G.adam_refresh_range(self.opt_g, 0, self.opt_g.flat().total, grad_scale=1.0 / self.world)
+            self.G.shadows_refreshed()
         else:
             self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
             self.G.refresh_shadows(force=True)

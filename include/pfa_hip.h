@@ -371,6 +371,14 @@ typedef struct pfa_shadow_desc {
 int pfa_shadow_blocks(int rows, int c1p, int c2p, int rows_p, int* same_blocks, int* tr_blocks);
 int pfa_weight_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int same_blocks, int tr_blocks, int dtype,
                             pfa_stream s);
+/* optim.Adam (train_gan.py:140-141) and the kernel-side weight copies in ONE pass over the parameters: the launch of
+ * pfa_weight_shadow_batch applies the update of pfa_adam (the same bits) to the master elements of each tile before it emits
+ * the copies - p, g (+ g2), m, v are the flat arenas, every descriptor's `master` points into p - and a second small launch
+ * updates the arena ranges that are not convolution weights (gaps_dev: ngaps pairs {first element, length}: BatchNorm gamma /
+ * beta, biases).  Replaces pfa_adam + pfa_weight_shadow_batch over a range of the arena (28 + 8 -> 28 + 4 bytes per parameter). */
+int pfa_adam_shadow_batch(const pfa_shadow_desc* descs_dev, int n, int tr_blocks, int dtype, const int64_t* gaps_dev, int ngaps,
+                          float* p, const float* g, const float* g2, float* m, float* v, float lr, float beta1, float beta2,
+                          float eps, int step, const int32_t* step_dev, float grad_scale, pfa_stream s);
 /* NCHW float32 [n][c][h][w] <-> NHWC `dtype` [n][h][w][cp] (cp >= c, pad lanes zero / ignored). */
 int pfa_pack_nhwc(const float* src, int n, int c, int h, int w, int cp, int dtype, void* dst, pfa_stream s);
 int pfa_unpack_nchw(const void* src, int n, int c, int h, int w, int cp, int dtype, float* dst, pfa_stream s);

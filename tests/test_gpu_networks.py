@@ -1015,6 +1015,51 @@ def test_eager_contexts_free_replaced_buffers_and_pinned_ones_shelve_them():
     assert len(ctx._shelf) == 1
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_adam_and_weight_copies_in_one_pass_equal_the_two_launches(precision):
+    """pfa_adam_shadow_batch (optim.Adam of train_gan.py:140-141 applied by the launch that emits the kernel-side weight
+    copies, BatchNorm parameters and biases by a small launch of their own) against pfa_adam + pfa_weight_shadow_batch on
+    the same state: parameters, both moments and every layer's two copies bit for bit - whole arena, two sub-ranges, the
+    discriminator's two gradient arenas - over two steps."""
+    def build():
+        torch.manual_seed(11)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda()
+        eg, ed = G.engine(precision), D.engine(precision, in_split=(3, 3))
+        og, od = pfa_gan.FusedAdam(G.parameters()), pfa_gan.FusedAdam(D.parameters())
+        for o in (og, od):
+            o.flat()
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        og.flat().grad.copy_(torch.randn(og.flat().total, device="cuda", generator=gen) * 1e-2)
+        od.flat().grad.copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2)
+        od.grad2().copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2)
+        return eg, ed, og, od
+    eg1, ed1, og1, od1 = build()
+    eg2, ed2, og2, od2 = build()
+    buckets, _ = eg1.grad_buckets()
+    for step in range(2):
+        # generator: bucket by bucket, as the trainer does it
+        og1.step_begin()
+        og2.step_begin()
+        for lo, hi in buckets:
+            eg1.adam_refresh_range(og1, lo, hi, grad_scale=0.5)
+            og2.step_range(lo, hi, grad_scale=0.5)
+            eg2.refresh_shadows_range(lo, hi)
+        # discriminator: whole arena, two gradient arenas
+        od1.step_begin()
+        ed1.adam_refresh_range(od1, 0, od1.flat().total, use_grad2=True)
+        od2.step(use_grad2=True)
+        ed2.refresh_shadows(force=True)
+        torch.cuda.synchronize()
+        for (e1, o1), (e2, o2) in (((eg1, og1), (eg2, og2)), ((ed1, od1), (ed2, od2))):
+            assert torch.equal(o1.flat().data, o2.flat().data), f"step {step}: parameters differ"
+            assert torch.equal(o1.m, o2.m) and torch.equal(o1.v, o2.v), f"step {step}: moments differ"
+            assert o1.steps == o2.steps == step + 1
+            for L1, L2 in zip(e1.layers, e2.layers):
+                assert torch.equal(L1.same, L2.same) and torch.equal(L1.tr, L2.tr), f"step {step}: copies of {L1.name} differ"
+    assert float((og1.flat().data - build()[2].flat().data).abs().max()) > 0        # (the update did something)
+
+
 def test_launch_list_records_calls_events_and_replays():
     """pfa_replay: library calls on two streams with an event between them, recorded once (they also run), re-issued by one
     C call; a struct argument is deep-copied; a failing op reports its index."""
