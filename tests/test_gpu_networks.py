@@ -1030,9 +1030,15 @@ def test_adam_and_weight_copies_in_one_pass_equal_the_two_launches(precision):
         for o in (og, od):
             o.flat()
         gen = torch.Generator(device="cuda").manual_seed(5)
-        og.flat().grad.copy_(torch.randn(og.flat().total, device="cuda", generator=gen) * 1e-2)
-        od.flat().grad.copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2)
-        od.grad2().copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2)
+
+        def real(flat):          # 1 on parameter elements, 0 on the alignment padding between them (gradients there are zero)
+            m = torch.zeros(flat.total, device="cuda")
+            for o, n in flat.slots.values():
+                m[o:o + n] = 1
+            return m
+        og.flat().grad.copy_(torch.randn(og.flat().total, device="cuda", generator=gen) * 1e-2 * real(og.flat()))
+        od.flat().grad.copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2 * real(od.flat()))
+        od.grad2().copy_(torch.randn(od.flat().total, device="cuda", generator=gen) * 1e-2 * real(od.flat()))
         return eg, ed, og, od
     eg1, ed1, og1, od1 = build()
     eg2, ed2, og2, od2 = build()
