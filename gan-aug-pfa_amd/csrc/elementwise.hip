@@ -856,6 +856,35 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
                 const int r = r0 + ty + 4 * k;
                 tile[ty + 4 * k][tx] = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
             }
+        } else if (d.c1r == d.c1p && d.c2r == d.c2p && (cr & 3) == 0) {
+            // no padded channels: the tile's rows are 256 contiguous bytes of the arenas - 16 lanes x 16 bytes per row, 16 rows
+            // per pass, every access a whole 16-byte vector as in k_adam
+            const AdamK ak = adam_consts(A.lr, A.b1, A.b2, A.eps, A.step, A.step_dev, A.grad_scale);
+            const size_t base = (size_t)(d.master - A.p);
+            const int q = tid & 15, rr = tid >> 4, cpq = cp0 + 4 * q;
+#pragma unroll
+            for (int k = 0; k < SH_TILE / 16; ++k) {
+                const int r = r0 + rr + 16 * k;
+                f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+                if (cpq < cp_tot && r < d.rows) {
+                    const size_t i = (base + ((size_t)r * 16 + tap) * cr + cpq) >> 2;
+                    pv = ((f32x4*)A.p)[i];
+                    f32x4 gv = ((const f32x4*)A.g)[i];
+                    f32x4 mv = __builtin_nontemporal_load((f32x4*)A.m + i), vv = __builtin_nontemporal_load((f32x4*)A.v + i);
+                    if (A.g2) gv += ((const f32x4*)A.g2)[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = pv[e], me = mv[e], ve = vv[e];
+                        adam_update(ak, pe, gv[e], me, ve);
+                        pv[e] = pe; mv[e] = me; vv[e] = ve;
+                    }
+                    ((f32x4*)A.p)[i] = pv;
+                    __builtin_nontemporal_store(mv, (f32x4*)A.m + i);
+                    __builtin_nontemporal_store(vv, (f32x4*)A.v + i);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[rr + 16 * k][4 * q + e] = pv[e];
+            }
         } else {
             const AdamK ak = adam_consts(A.lr, A.b1, A.b2, A.eps, A.step, A.step_dev, A.grad_scale);
             const size_t base = (size_t)(d.master - A.p);           // the weight's first element in the arenas

@@ -30,17 +30,28 @@ def kernel_resources(lib=LIB):
                 continue
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], check=True,
                                    stdout=subprocess.PIPE, text=True).stdout
-            cur = None
+            # one YAML list item per kernel ("  - .agpr_count: ..." opens it: the keys are in alphabetical order, so some of a
+            # kernel's keys precede its .name)
+            entry = None
+            entries = []
             for line in notes.splitlines():
-                m = re.match(r"\s+\.(\w+):\s+(\S+)", line)
+                m = re.match(r"(\s+)(- )?\.(\w+):\s+(\S+)", line)
                 if not m:
                     continue
-                k, v = m.groups()
-                if k == "name" and v.startswith("_Z"):
-                    cur = out.setdefault(v, {})
-                elif cur is not None and k in ("private_segment_fixed_size", "vgpr_count", "sgpr_count", "vgpr_spill_count",
-                                               "sgpr_spill_count", "group_segment_fixed_size", "agpr_count"):
-                    cur[k] = int(v)
+                _, opens, k, v = m.groups()
+                if opens and k == "agpr_count":
+                    entry = {}
+                    entries.append(entry)
+                if entry is None:
+                    continue
+                if k == "name":
+                    entry.setdefault("name", v)
+                elif k in ("private_segment_fixed_size", "vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count",
+                           "group_segment_fixed_size", "agpr_count"):
+                    entry.setdefault(k, int(v))
+            for e in entries:
+                if e.get("name", "").startswith("_Z"):
+                    out[e.pop("name")] = e
     names = list(out)
     filt = shutil.which("c++filt") or shutil.which("llvm-cxxfilt")
     dem = subprocess.run([filt] + names, stdout=subprocess.PIPE, text=True).stdout.splitlines() if filt else names
