@@ -835,7 +835,11 @@ template <typename T, bool ADAM>
 __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_desc* __restrict__ descs, int n, const AdamArenas A) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int GROUPS = SH_TILE / CH;                  // 16-byte groups per tile row
-    __shared__ float tile[SH_TILE][SH_TILE + 1];
+    // 64 x 64 floats, element (row, col) at column (col + row) % 64: rows and columns both fall on distinct banks without a
+    // padding column - 16,384 bytes exactly, what a CU has left beside a 144-KiB patch-kernel workgroup of the backward chain
+    // this launch runs under (with 16,640 bytes the two could not share a CU)
+    __shared__ float tile_[SH_TILE * SH_TILE];
+    auto tile = [&](int row, int col) -> float& { return tile_[row * SH_TILE + ((col + row) & (SH_TILE - 1))]; };
     const int tid = threadIdx.x, lane = tid & 63;
     const int mine = lane < n ? descs[lane].tr_blk0 : 0x7fffffff;
     const int l = __popcll(__ballot(mine <= (int)blockIdx.x)) - 1;
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
 #pragma unroll
             for (int k = 0; k < SH_TILE / 4; ++k) {
                 const int r = r0 + ty + 4 * k;
-                tile[ty + 4 * k][tx] = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
+                tile(ty + 4 * k, tx) = (c >= 0 && r < d.rows) ? d.master[((size_t)r * 16 + tap) * cr + c] : 0.f;
             }
         } else if (d.c1r == d.c1p && d.c2r == d.c2p && (cr & 3) == 0) {
             // no padded channels: the tile's rows are 256 contiguous bytes of the arenas - 16 lanes x 16 bytes per row, 16 rows
@@ -883,7 +887,7 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
                     __builtin_nontemporal_store(vv, (f32x4*)A.v + i);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) tile[rr + 16 * k][4 * q + e] = pv[e];
+                for (int e = 0; e < 4; ++e) tile(rr + 16 * k, 4 * q + e) = pv[e];
             }
         } else {
             const AdamK ak = adam_consts(A.lr, A.b1, A.b2, A.eps, A.step, A.step_dev, A.grad_scale);
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
                     __builtin_nontemporal_store(me, A.m + i);
                     __builtin_nontemporal_store(ve, A.v + i);
                 }
-                tile[ty + 4 * k][tx] = pe;
+                tile(ty + 4 * k, tx) = pe;
             }
         }
     }
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
             if (r < d.rows && cpb < cp_tot) {
                 Chunk<T> o;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) o.v[e] = tile[line][g * CH + e];
+                for (int e = 0; e < CH; ++e) o.v[e] = tile(line, g * CH + e);
                 o.store(same + ((size_t)r * 16 + tap) * cp_tot + cpb);
             }
         }
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void k_shadow_fused_batch(const pfa_shadow_des
             if (cp < cp_tot && rb < d.rows_p) {
                 Chunk<T> o;
 #pragma unroll
-                for (int e = 0; e < CH; ++e) o.v[e] = tile[g * CH + e][line];
+                for (int e = 0; e < CH; ++e) o.v[e] = tile(g * CH + e, line);
                 o.store(trp + ((size_t)cp * 16 + tap) * d.rows_p + rb);
             }
         }
