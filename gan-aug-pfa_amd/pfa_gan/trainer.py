@@ -35,7 +35,9 @@ DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"  
 # dL/dpre from the launch that computes dL/dfake: measured -0.2 % at 256x256 and -0.9 % at 512x512 (the loss-only L1 pass on
 # the side stream collides with the HBM-bound first launches of the generator backward): off
 L1_FUSED = _os.environ.get("PFA_L1_FUSED", "0") != "0"
-ADAM_SHADOW_FUSED = _os.environ.get("PFA_ADAM_SHADOW_FUSED", "1") != "0"   # Adam + weight copies in one pass (A/B switch)
+# Adam + weight copies in one pass: 25 % less kernel time alone (0.27 against 0.36 ms per step on one stream), but in the
+# three-stream step +-0 at 256x256 and -0.8 % at 512x512 (three same-box pairs each): built, tested bit for bit, off
+ADAM_SHADOW_FUSED = _os.environ.get("PFA_ADAM_SHADOW_FUSED", "0") != "0"
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
