@@ -41,31 +41,6 @@ ADAM_SHADOW_FUSED = _os.environ.get("PFA_ADAM_SHADOW_FUSED", "0") != "0"
 LAST_BUCKET_MAIN = _os.environ.get("PFA_LAST_BUCKET_MAIN", "1") != "0"   # the last bucket's update on the main stream (A/B switch)
 
 
-# Developer experiment (PFA_SIDE_CUS / PFA_SIDE2_CUS = n > 0): the side streams are created with a CU mask of n of the 256
-# CUs (hipExtStreamCreateWithCUMask; the mask bits are dealt over the XCDs symmetrically), i.e. the GPU is shared between the
-# main chain and the side work in SPACE instead of by time-slicing workgroups.  0 = ordinary streams (the default).
-SIDE_CUS = int(_os.environ.get("PFA_SIDE_CUS", "0"))
-SIDE2_CUS = int(_os.environ.get("PFA_SIDE2_CUS", "0"))
-_masked_streams = []          # (the HIP streams behind torch.cuda.ExternalStream objects live as long as the process)
-
-
-def _side_stream(dev, ncus):
-    if ncus <= 0:
-        return torch.cuda.Stream(device=dev)
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * 8)()
-    for i in range(min(ncus, 256)):
-        words[i // 32] |= 1 << (i % 32)
-    st = ctypes.c_void_p()
-    with torch.cuda.device(dev):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
-    if rc != 0 or not st.value:
-        raise PfaError(f"hipExtStreamCreateWithCUMask failed (rc={rc})")
-    _masked_streams.append(st)
-    return torch.cuda.ExternalStream(st.value, device=dev)
-
-
 class FusedAdam(torch.optim.Optimizer):
     """optim.Adam(lr, betas) semantics (weight_decay 0, amsgrad off) as one pfa_adam launch per network.
 
@@ -235,8 +210,8 @@ class GanTrainer:
         self.nsteps = 0
         self.use_graph = use_graph
         # second HIP stream: parameter-gradient kernels run under the dgrad/BatchNorm chain, D(real) under G forward
-        self.side = _side_stream(dev, SIDE_CUS) if overlap else None
-        self.side2 = _side_stream(dev, SIDE2_CUS) if overlap else None
+        self.side = torch.cuda.Stream(device=dev) if overlap else None
+        self.side2 = torch.cuda.Stream(device=dev) if overlap else None
         # optional fourth stream: the generator's weight gradients alternate between `side` and this one (PFA_WGRAD_STREAMS=2)
         self.side3 = torch.cuda.Stream(device=dev) if overlap and WGRAD_STREAMS == 2 else None
         self._ev_real_fwd = torch.cuda.Event() if overlap else None
