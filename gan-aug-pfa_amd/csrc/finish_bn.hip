@@ -20,6 +20,7 @@ constexpr int FB_KEEP = 4, FB_MAXJ = 8;      // up to 2048 rows: slice sums stay
 struct FinBnK {
     const float* slab;
     int splitk, rows, n;                  // planes, rows (= output pixels), columns (= slab row length)
+    int serial;                           // A/B (pfa_set_knob(1, 1024)): one slice per round trip, as before round 3
     // ---- forward
     const float *gamma, *beta;
     float eps, momentum;
@@ -57,7 +58,19 @@ __device__ __forceinline__ void sum_slices(const FinBnK& p, int r, int c0, float
     const float* src = p.slab + (size_t)r * p.n + c0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) t[e] = 0.f;
-    for (int s = 0; s < p.splitk; ++s) {
+    // four slices' loads in flight at a time (a thread's chain of dependent round trips is what bounds these launches);
+    // the additions stay in ascending slice order
+    int s = 0;
+    for (; !p.serial && s + 4 <= p.splitk; s += 4) {
+        float u[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load8(src + (s + k) * plane, u[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += u[k][e];
+    }
+    for (; s < p.splitk; ++s) {
         float u[8];
         load8(src + s * plane, u);
 #pragma unroll
@@ -311,7 +324,7 @@ extern "C" int pfa_finish_bn_fwd(const float* slab, int splitk, int rows, int n,
     PFA_REQUIRE(raw && scale && shift && ld >= n && ld % 8 == 0 && (running_mean == nullptr) == (running_var == nullptr),
                 "pfa_finish_bn_fwd: bad arguments");
     FinBnK k{};
-    k.slab = slab; k.splitk = splitk; k.rows = rows; k.n = n;
+    k.slab = slab; k.splitk = splitk; k.rows = rows; k.n = n; k.serial = (pfa_knob(1) & 1024) != 0;
     k.gamma = gamma; k.beta = beta; k.eps = eps; k.momentum = momentum; k.repeats = repeats;
     k.running_mean = running_mean; k.running_var = running_var; k.nbt = num_batches_tracked;
     k.raw = (char*)raw; k.out_l = (char*)out_l; k.out_r = (char*)out_r; k.ld = ld; k.slope = slope;
@@ -331,7 +344,7 @@ extern "C" int pfa_finish_bn_bwd(const float* slab, int splitk, int rows, int n,
                 (scale == nullptr) == (shift == nullptr) && (mean == nullptr) == (invstd == nullptr),
                 "pfa_finish_bn_bwd: bad arguments");
     FinBnK k{};
-    k.slab = slab; k.splitk = splitk; k.rows = rows; k.n = n;
+    k.slab = slab; k.splitk = splitk; k.rows = rows; k.n = n; k.serial = (pfa_knob(1) & 1024) != 0;
     k.n1 = n1; k.plain = (char*)plain; k.ld1 = ld1; k.fraw = (const char*)raw; k.g2 = (const char*)g2;
     k.act1 = act1; k.act2 = act2; k.slope = slope;
     k.scale = (float*)scale; k.shift = (float*)shift; k.mean = (float*)mean; k.invstd = (float*)invstd;

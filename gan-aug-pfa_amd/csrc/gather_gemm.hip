@@ -629,6 +629,32 @@ struct FinishFuse {
     const float* mean;
     const float* invstd;
 };
+// v[ps] += the slices' values of pass ps, in ascending slice order; KU slices x PS passes of loads in flight at a time
+// (a block with few passes would otherwise wait one round trip per slice)
+template <int KU, int PS>
+__device__ __forceinline__ void sum_planes(const float* src0, size_t pstride, size_t plane, int splitk, const bool* live, f32x4* v) {
+    int k = 0;
+    if (KU > 1) {
+        for (; k + KU <= splitk; k += KU) {
+            f32x4 t[KU][PS];
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps)
+                    if (live[ps]) t[u][ps] = *(const f32x4*)(src0 + ps * pstride + (k + u) * plane);
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int ps = 0; ps < PS; ++ps)
+                    if (live[ps]) v[ps] += t[u][ps];
+        }
+    }
+    for (; k < splitk; ++k) {
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps)
+            if (live[ps]) v[ps] += *(const f32x4*)(src0 + ps * pstride + k * plane);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restrict__ slab, int splitk, int pixels,
                                                            int n, int n1, const float* __restrict__ bias, int act,
@@ -663,7 +689,7 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
         }
     }
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
-    const size_t row0 = (size_t)blockIdx.x * rpp * passes;
+    const size_t row0 = (size_t)blockIdx.x * rpp * (passes < 0 ? -passes : passes);
     const size_t plane = (size_t)pixels * n;
     // All passes of the block are loaded together (the pass loop is unrolled, so every pass's read of slice k is in
     // flight at once): a block is latency-, not bandwidth-bound.  The sum over slices stays in ascending k per element.
@@ -673,15 +699,16 @@ __global__ __launch_bounds__(256) void k_splitk_finish_vec(const float* __restri
     bool live[FIN_PASSES];
 #pragma unroll
     for (int ps = 0; ps < FIN_PASSES; ++ps) {
-        live[ps] = ps < passes && row0 + (size_t)ps * rpp + rsub < (size_t)pixels;
+        live[ps] = ps < (passes < 0 ? -passes : passes) && row0 + (size_t)ps * rpp + rsub < (size_t)pixels;
         v[ps] = bv;
     }
     const float* src0 = slab + (row0 + rsub) * n + c0;
-    for (int k = 0; k < splitk; ++k) {
-#pragma unroll
-        for (int ps = 0; ps < FIN_PASSES; ++ps)
-            if (live[ps]) v[ps] += *(const f32x4*)(src0 + (size_t)ps * rpp * n + k * plane);
-    }
+    const size_t pstride = (size_t)rpp * n;
+    if (passes < 0) sum_planes<1, FIN_PASSES>(src0, pstride, plane, splitk, live, v);      // (A/B: knob 1 bit 1024)
+    else if (passes == 1) sum_planes<8, 1>(src0, pstride, plane, splitk, live, v);
+    else if (passes == 2) sum_planes<4, 2>(src0, pstride, plane, splitk, live, v);
+    else if (passes <= 4) sum_planes<2, 4>(src0, pstride, plane, splitk, live, v);
+    else sum_planes<1, FIN_PASSES>(src0, pstride, plane, splitk, live, v);
 #pragma unroll
     for (int ps = 0; ps < FIN_PASSES; ++ps) {
         if (!live[ps]) continue;
@@ -1165,16 +1192,17 @@ static int splitk_finish(const float* slab, int slab_ld, int splitk, int pixels,
     const bool small = !vec && n1 >= n && ld1 <= 16 && !psum;
     const int passes = vec ? finish_passes(n, pixels) : 1;
     const int rpb = vec ? (256 / (n / 4)) * passes : 64;
+    const int kpasses = (pfa_knob(1) & 1024) ? -passes : passes;
     const int tiles = (pixels + rpb - 1) / rpb;
     if (ntiles_stat) *ntiles_stat = tiles;
     hipStream_t st = (hipStream_t)s;
     if (vec) {
         if (dtype == PFA_BF16)
             hipLaunchKernelGGL(k_splitk_finish_vec<bf16_t>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2, fz);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, kpasses, scale, shift, act2, fz);
         else
             hipLaunchKernelGGL(k_splitk_finish_vec<float>, dim3(tiles), dim3(256), 0, st, slab, splitk, pixels, n, n1,
-                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, passes, scale, shift, act2, fz);
+                               bias, act, slope, (char*)out1, ld1, (char*)out2, ld2, psum, psq, n / 4, kpasses, scale, shift, act2, fz);
     } else if (small) {
         const int grid = (int)(((size_t)pixels * ld1 + 255) / 256);
         if (dtype == PFA_BF16)

@@ -53,7 +53,8 @@ uint64_t pfa_launch_count(void);
 /* Developer tuning knobs for A/B measurements (never needed for correctness). id 0: gather tile (0 = automatic,
  * 4 = 256x128 two-stage / 8 = 256x128 ring where n >= 128, 6 = 128x64 everywhere, 7 = no ring tiles); id 1: in-kernel ablation bits (1 no stores, 2 no statistics, 4 no MFMA, 8 no DMA,
  * 32 ring: a stage's DMA in one burst; 64 fused backward epilogue without its raw / g2 traffic; 128 staggered ring: no LDS fragment reads
- * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set));
+ * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set); 1024 the slice-combining passes
+ * (k_splitk_finish_vec, pfa_finish_bn_*) wait one round trip per slice, as before round 3);
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
