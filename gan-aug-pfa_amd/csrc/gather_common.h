@@ -163,6 +163,9 @@ __device__ __forceinline__ void gather_epilogue(const GatherK& p, f32x4 (&acc)[F
     const float neg = act_neg(p.act, p.slope), neg1 = act_neg(p.fuse_act1, p.slope), neg2 = act_neg(p.fuse_act2, p.slope);
 
     if (p.splitk > 1) {
+#ifdef PFA_RING_DIAG      // diagnostic build: knob 1 bit 1 drops the partial planes' stores
+        if (p.dbg & 1) return;
+#endif
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int nbase = n0 + wn * TN + a * 16 + 4 * kk;

@@ -489,14 +489,24 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                     sp = false;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef PFA_RING_DIAG      // diagnostic build (make CXXFLAGS+=-DPFA_RING_DIAG): knob 1 bits 128 / 4 drop the ring's fragment reads / MFMAs
+                if (!(p.dbg & 128)) {
+                    read_half_raw(fA, buf, 0, 0);
+                    read_half_raw(fA, buf, 1, 1);
+                }
+#else
                 read_half_raw(fA, buf, 0, 0);
                 read_half_raw(fA, buf, 1, 1);
+#endif
                 PFA_WAIT_LGKM(FN + FM);
                 pin_half(fA, 0);
 #pragma unroll
                 for (int a = 0; a < FN; ++a)
 #pragma unroll
                     for (int b = 0; b < FM; ++b) {
+#ifdef PFA_RING_DIAG
+                        if (!(p.dbg & 4))
+#endif
                         acc[a][b] = Mma<T>::run(fA.wf[0][a], fA.af[0][b], acc[a][b]);
                         const int idx = a * FM + b;
                         const int lo = (idx * NPIECE) / MF0, hi = ((idx + 1) * NPIECE) / MF0;   // pieces due after this MFMA
@@ -513,6 +523,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2)
                 __builtin_amdgcn_sched_barrier(0);
                 PFA_WAIT_LGKM(0);
                 pin_half(fA, 1);
+#ifdef PFA_RING_DIAG
+                if (!(p.dbg & 4))
+#endif
                 mfma_half(fA, 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
