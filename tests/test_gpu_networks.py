@@ -404,6 +404,95 @@ def test_data_parallel_code_path_single_rank_rccl(golden):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["three-streams", "one-stream", "resident-inputs", "bf16-payload"])
+def test_data_parallel_stream_order_under_a_slow_collective(monkeypatch, mode):
+    """What neither gloo (host-blocking waits) nor a 1-rank RCCL group (an all-reduce that changes nothing) can show: that
+    every consumer of a gradient range is ordered behind that range's collective, and every collective behind the range's
+    last producer, by STREAM dependencies alone.  torch.distributed.all_reduce is replaced by an emulation with NCCL's
+    stream semantics - the collective runs on a communicator stream that waits for the calling stream; work.wait() makes
+    the then-current stream wait, never the host - which is slow (a matrix product in front of it) and mixes the range
+    (t += roll(t) / 2: "the other rank's gradient"; not a pure scaling, which Adam would not notice).  The same steps with
+    a collective that synchronises the whole device before and after itself are ordered trivially; the two runs must
+    end in the same parameters, bit for bit.  An update that ran ahead of its collective, or a collective that ran ahead of
+    a weight gradient, ends elsewhere."""
+    import torch.distributed as dist
+    comm = torch.cuda.Stream()
+    ballast = torch.randn(2048, 2048, device="cuda")
+    state = {"trusted": False, "calls": []}
+
+    class _Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            if self.ev is not None:
+                torch.cuda.current_stream().wait_event(self.ev)
+            return True
+
+    def mix(t):
+        t.add_(torch.roll(t, 1), alpha=0.5)
+
+    def all_reduce(t, op=None, group=None, async_op=False):
+        state["calls"].append((t.numel(), bool(async_op)))
+        if state["trusted"]:
+            torch.cuda.synchronize()
+            mix(t)
+            torch.cuda.synchronize()
+            return _Work(None) if async_op else None
+        cur = torch.cuda.current_stream()
+        comm.wait_stream(cur)
+        with torch.cuda.stream(comm):
+            torch.mm(ballast, ballast)                     # ~0.2 ms: the collective is still running when the host moves on
+            mix(t)
+            ev = torch.cuda.Event()
+            ev.record(comm)
+        if async_op:
+            return _Work(ev)
+        cur.wait_event(ev)
+        return None
+
+    monkeypatch.setattr(dist, "all_reduce", all_reduce)
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 2)
+    name, nd, ngf, ndf, n, h, _ = STEP_CASES[0]
+    steps = 3
+    batches = [(torch.from_numpy(fill.uniform(f"order.a{i}", (n, 3, h, h), seed=77)).cuda(),
+                torch.from_numpy(fill.uniform(f"order.b{i}", (n, 3, h, h), seed=77)).cuda()) for i in range(steps)]
+
+    def run(trusted):
+        state["trusted"], state["calls"] = trusted, []
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+        load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+        load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+        tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=object(), overlap=mode != "one-stream",
+                                inputs_resident=mode == "resident-inputs",
+                                grad_payload="bf16" if mode == "bf16-payload" else None)
+        assert tr.world == 2
+        torch.cuda.synchronize()
+        if mode == "resident-inputs":
+            packed = [(tr.pack(a), tr.pack(b)) for a, b in batches]
+            torch.cuda.synchronize()
+            out = [tr.step_packed(a, b) for a, b in packed]        # no host synchronisation between the steps
+        else:
+            out = [tr.step(a, b) for a, b in batches]
+        losses = torch.stack([l.clone() for l in out]).cpu()
+        torch.cuda.synchronize()
+        sd = {f"{p}.{k}": v.detach().cpu().clone() for p, m in (("g", G), ("d", D)) for k, v in m.state_dict().items()}
+        return losses, sd, list(state["calls"]), (tr.G.flat.total, tr.Dn.flat.total)
+
+    l0, s0, c0, (gtot, dtot) = run(True)
+    l1, s1, c1, _ = run(False)
+    assert c0 == c1, "both runs issue the same collectives"
+    # every gradient element crosses the ranks once per step; the discriminator's two arenas (D(real)'s leaves early, under
+    # the generator's forward) travel separately where the step runs on three streams
+    assert sum(c[0] for c in c1) in (steps * (gtot + dtot), steps * (gtot + 2 * dtot))
+    if mode != "one-stream":
+        assert sum(1 for c in c1 if c[1]) >= steps * 3, "the bucketed collectives are asynchronous"
+    assert torch.isfinite(l1).all()
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), f"{k}: differs from the trivially ordered run by {(s0[k].float() - s1[k].float()).abs().max():.3e}"
+
+
 @pytest.mark.parametrize("precision,n,h", [("fp32", 1, 128), ("bf16", 1, 256), ("bf16", 3, 128), ("fp32", 2, 256)],
                          ids=lambda v: str(v))
 def test_full_size_step_vs_oracle(precision, n, h):
