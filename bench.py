@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--replay", action="store_true",
                     help="GanTrainer(use_graph='replay'): the step's launches recorded once as launch lists and re-issued "
                          "from C (pfa_replay) on the same three streams")
+    ap.add_argument("--collectives", choices=["torch", "c"], default=None,
+                    help="N > 1: transport of the gradient all-reduces - torch.distributed (default) or the library's RCCL "
+                         "communicator (pfa_comm_* / pfa_allreduce; GanTrainer(collectives='c'))")
     ap.add_argument("--grad-bf16", action="store_true",
                     help="N > 1: the gradient all-reduces carry bfloat16 (GanTrainer(grad_payload='bf16')); default float32")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
@@ -321,17 +324,18 @@ def comm_diagnostics(trainer, pool, args, world, barrier, ms_with):
     ranges = [("G " + "/".join(str(x) for x in w), hi - lo) for (lo, hi), w in zip(buckets, whens)]
     ranges += [("D(real) arena", d_total), ("D(fake) c4..c5", d_total - d_lo), ("D(fake) c1..c3", d_lo)]
     probe = []
+    reduce_ = trainer.ccomm.allreduce if trainer.ccomm is not None else dist.all_reduce     # the step's own transport
     for name, n in ranges:
         if n <= 0:
             continue
         buf = torch.zeros(n, dtype=torch.bfloat16 if trainer.grad_payload else torch.float32, device="cuda")
         for _ in range(2):
-            dist.all_reduce(buf)
+            reduce_(buf)
         barrier()
         t0 = time.perf_counter()
         reps = 5
         for _ in range(reps):
-            dist.all_reduce(buf)
+            reduce_(buf)
         torch.cuda.synchronize()
         ms = tmax(1e3 * (time.perf_counter() - t0) / reps)
         probe.append(dict(range=name, mbytes=round(n * esize / 1e6, 2), ms=round(ms, 3),
@@ -353,6 +357,7 @@ def comm_diagnostics(trainer, pool, args, world, barrier, ms_with):
                 payload="bf16" if trainer.grad_payload else "f32",
                 bytes_per_step_mb=round((g_total + 2 * d_total) * esize / 1e6, 1),
                 allreduce_alone=probe, backend=dist.get_backend(),
+                transport="pfa_allreduce" if trainer.ccomm is not None else "torch.distributed.all_reduce",
                 note="comm_cost = headline ms/step - the same loop without the gradient all-reduces; allreduce_alone: each "
                      "gradient range of the step reduced by itself (5 back-to-back calls)")
 
@@ -510,7 +515,7 @@ def main():
     # inputs_resident: the batches below are packed and complete in HBM before the first step (the bench contract)
     trainer = pfa_gan.GanTrainer(gen, disc, precision=args.precision, process_group=pg, use_graph="auto" if args.auto_graph else ("replay" if args.replay else args.graph),
                                  overlap=not args.no_overlap, inputs_resident=not args.no_early_real,
-                                 grad_payload="bf16" if args.grad_bf16 else None)
+                                 grad_payload="bf16" if args.grad_bf16 else None, collectives=args.collectives)
     if world > 1:                                    # rank 0's parameters and buffers are the job's
         for t in [trainer.opt_g.flat().data, trainer.opt_d.flat().data] + list(gen.buffers()) + list(disc.buffers()):
             torch.distributed.broadcast(t, 0)
@@ -572,6 +577,8 @@ def main():
                                    f"NLayerDiscriminator ndf=64, BatchNorm, BCE+100*L1, 2x Adam), batch {args.batch}/GPU",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "grad_payload": "bf16" if trainer.grad_payload else "f32",
+                       "collectives": None if world == 1 else ("pfa_allreduce (library communicator)" if trainer.ccomm is not None
+                                                              else "torch.distributed"),
                        "launch": "hipGraph x3 segments" if trainer.use_graph is True else
                                  (("launch lists (pfa_replay), " if trainer.use_graph == "replay" else "eager, ") +
                                   ("3 HIP streams" if not args.no_overlap else "1 HIP stream")),

@@ -3,3 +3,4 @@ from .models import NLayerDiscriminator, UNetGenerator, UnetSkipConnectionBlock 
 from .trainer import (FusedAdam, GanTrainer, allreduce_mean_grads, broadcast_model, load_training_state,  # noqa: F401
                       train_gan_one_epoch)
 from .inference import TilePipeline  # noqa: F401
+from .kernels import Comm  # noqa: F401

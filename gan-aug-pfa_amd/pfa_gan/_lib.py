@@ -138,6 +138,12 @@ PROTOTYPES = {
     "pfa_finish_bn_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p]),
+    "pfa_comm_unique_id": (c_int, [c_void_p, c_int]),
+    "pfa_comm_create": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "pfa_comm_destroy": (c_int, [c_void_p]),
+    "pfa_comm_size": (c_int, [c_void_p]),
+    "pfa_comm_rank": (c_int, [c_void_p]),
+    "pfa_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "pfa_replay_index": (c_int, [c_char_p]),
     "pfa_replay": (c_int, [c_void_p, c_int, POINTER(c_int)]),
 }

@@ -620,3 +620,50 @@ def unpack_u8(x, c, mul=0.5, add=0.5, out=None):
 
 def fill_zero(t):
     check(lib().pfa_fill_zero(ptr(t), t.numel() * t.element_size(), stream()), "pfa_fill_zero")
+
+
+# ------------------------------------------------------------------------------- data-parallel exchange (pfa_comm_*)
+class Comm:
+    """An RCCL communicator behind the C boundary (include/pfa_hip.h, "data-parallel exchange"): the transport a host
+    without torch.distributed would use, and the one launch lists can hold.  allreduce() is ordered on the current stream
+    like every other launch: no handle, no separate communicator stream."""
+    ID_BYTES = 128
+
+    def __init__(self, handle, nranks, rank):
+        self.handle, self.nranks, self.rank = handle, nranks, rank
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(Comm.ID_BYTES)
+        check(lib().pfa_comm_unique_id(buf, Comm.ID_BYTES), "pfa_comm_unique_id")
+        return bytes(buf.raw)
+
+    @classmethod
+    def create(cls, ident, nranks, rank):
+        """Collective over the ranks; the calling thread's current device is the rank's GPU."""
+        out = ctypes.c_void_p()
+        check(lib().pfa_comm_create(ident, len(ident), nranks, rank, ctypes.byref(out)), "pfa_comm_create")
+        return cls(out.value, nranks, rank)
+
+    @classmethod
+    def from_process_group(cls, pg=None):
+        """One communicator over the ranks of a torch.distributed group; the group only carries the identifier."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(pg), dist.get_world_size(pg)
+        ident = [cls.unique_id() if rank == 0 else None]
+        src = dist.get_global_rank(pg, 0) if pg is not None and pg is not dist.group.WORLD else 0
+        dist.broadcast_object_list(ident, src=src, group=pg)
+        return cls.create(ident[0], world, rank)
+
+    def allreduce(self, t):
+        """t (contiguous float32 / bfloat16 device tensor) := sum over the ranks, in place, on the current stream."""
+        _require_cuda(t)
+        if not t.is_contiguous():
+            raise _lib.PfaError("Comm.allreduce: the range must be contiguous")
+        check(lib().pfa_allreduce(self.handle, ptr(t), t.numel(), dt_code(t.dtype), stream()), "pfa_allreduce")
+
+    def close(self):
+        if self.handle is not None:
+            h, self.handle = self.handle, None
+            check(_lib.lib().pfa_comm_destroy(h), "pfa_comm_destroy")
+

@@ -161,7 +161,7 @@ class GanTrainer:
     """Owns the engines, contexts and optimizers of one (generator, discriminator) pair on one GPU."""
 
     def __init__(self, gen, disc, opt_g=None, opt_d=None, precision="bf16", lambda_l1=LAMBDA_L1, process_group=None,
-                 use_graph=False, overlap=True, inputs_resident=False, grad_payload=None):
+                 use_graph=False, overlap=True, inputs_resident=False, grad_payload=None, collectives=None):
         """inputs_resident: the caller guarantees that the (packed) batches handed to step_packed() are complete in
         device memory before the call - e.g. a pool of resident batches, or batches produced on a stream the caller
         has synchronised.  The D(real) pass of a step then no longer waits for the previous step's generator update
@@ -169,6 +169,9 @@ class GanTrainer:
         grad_payload: None = the gradient all-reduces carry float32 (the default); "bf16" = every range is cast to
         bfloat16 for the collective and back (half the bytes over xGMI: 89 MB instead of 178 MB per step and rank for the
         default networks; the sum then carries bf16 rounding, like torch DDP's bf16 compression hook).
+        collectives: "torch" (default; PFA_COLLECTIVES overrides) = torch.distributed.all_reduce on the group (RCCL's
+        own stream, work handles); "c" = the library's communicator (pfa_comm_* / pfa_allreduce: one RCCL communicator
+        over the group's ranks, every collective ordered on the stream that issues it).
         use_graph: False = eager launch on three streams from Python; "replay" = the same launches, streams and
         dependencies recorded once per segment as launch lists and re-issued from C (pfa_replay): the host cost of a
         step drops from ~2.5 ms to ~0.2 ms, static shapes and addresses as for graphs; True = the step's three segments
@@ -197,6 +200,11 @@ class GanTrainer:
         self._payload = {}
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self._g_reduced = False
+        collectives = collectives or _os.environ.get("PFA_COLLECTIVES", "torch")
+        if collectives not in ("torch", "c"):
+            raise PfaError(f"GanTrainer(collectives={collectives!r}): 'torch' or 'c'")
+        # (created here, while every rank is in the constructor: the communicator's set-up is itself a collective)
+        self.ccomm = K.Comm.from_process_group(process_group) if process_group is not None and collectives == "c" else None
         self.skip_collectives = False        # bench.py's comm-off timing pass (never set in training)
         dev = self.G.device
         self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
@@ -540,12 +548,25 @@ class GanTrainer:
                 def wait(self_inner):
                     pass
             return _Done() if async_op else None
-        if self.grad_payload is None:
+        if self.grad_payload is None and self.ccomm is None:
             return torch.distributed.all_reduce(t, group=self.pg, async_op=async_op)
-        buf = self._payload.get(key)
-        if buf is None or buf.numel() != t.numel():
-            buf = self._payload[key] = torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
-        buf.copy_(t)
+        buf = None
+        if self.grad_payload is not None:
+            buf = self._payload.get(key)
+            if buf is None or buf.numel() != t.numel():
+                buf = self._payload[key] = torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
+            buf.copy_(t)
+        if self.ccomm is not None:
+            # the library's communicator: the collective is ordered on the current stream (behind the range's producers,
+            # which the caller has made this stream wait for; in front of whatever this stream does next)
+            self.ccomm.allreduce(t if buf is None else buf)
+            if buf is not None:
+                t.copy_(buf)
+
+            class _InStream:
+                def wait(self_inner):
+                    pass
+            return _InStream() if async_op else None
         work = torch.distributed.all_reduce(buf, group=self.pg, async_op=True)
 
         class _Back:

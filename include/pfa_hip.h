@@ -413,6 +413,27 @@ int pfa_finish_bn_bwd(const float* slab, int splitk, int rows, int n, int n1, vo
                       const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, int dtype,
                       void* dr, int ld2, pfa_stream s);
 
+/* ------------------------------------------------------------------ data-parallel exchange (one process per GPU)
+ * Replaces, for this path, the gradient all-reduce DistributedDataParallel runs behind loss.backward()
+ * (/root/reference/train_gan.py:62-63,70-71 under a torch.distributed launcher; BASELINE config 3): an RCCL communicator
+ * over the ranks and an in-place SUM-all-reduce of a gradient range on the caller's stream - stream-ordered like every
+ * other entry point, so the range's last producer and its first consumer are ordered by the stream (or by events) and a
+ * launch list can hold the call.  The mean is the optimizer's grad_scale = 1 / ranks (pfa_adam).  RCCL is resolved with
+ * dlopen at the first call (no link-time dependency; inside a PyTorch process the already-mapped librccl.so.1 is used).
+ *   pfa_comm_unique_id  rank 0 draws the 128-byte identifier; the host transports it to the other ranks (any channel)
+ *   pfa_comm_create     every rank, with its device current (hipSetDevice): collective over the ranks
+ *   pfa_allreduce       buf[0..count) of dtype PFA_F32 | PFA_BF16 := sum over the ranks, in place, on stream s; every
+ *                       rank issues the same calls in the same order
+ * Measured on one rank only in this repository (a one-GPU box cannot hold two ranks of one communicator); the Python host
+ * keeps torch.distributed as its default transport (GanTrainer(collectives="c") selects this one). */
+typedef struct pfa_comm pfa_comm;
+int pfa_comm_unique_id(void* out, int bytes);                 /* bytes must be 128 */
+int pfa_comm_create(const void* unique_id, int bytes, int nranks, int rank, pfa_comm** out);
+int pfa_comm_destroy(pfa_comm* c);
+int pfa_comm_size(const pfa_comm* c);
+int pfa_comm_rank(const pfa_comm* c);
+int pfa_allreduce(pfa_comm* c, void* buf, int64_t count, int dtype, pfa_stream s);
+
 /* ------------------------------------------------------------------ launch lists
  * A training step is ~210 launches on three streams with the same arguments every iteration (static shapes, persistent
  * buffers).  Issuing them from Python costs ~2.5 ms per step; a launch list is that sequence recorded once - every call of

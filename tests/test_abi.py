@@ -32,6 +32,15 @@ def test_argument_validation_needs_no_gpu():
     assert b"struct_size" in _lib.lib().pfa_last_error_string()
     w = _lib.WgradArgs()
     assert _lib.lib().pfa_wgrad(w, None) < 0
+    # the exchange step's entry points reject bad arguments before RCCL is even looked for
+    import ctypes
+    out = ctypes.c_void_p()
+    assert _lib.lib().pfa_comm_create(None, 128, 2, 0, ctypes.byref(out)) < 0
+    assert _lib.lib().pfa_comm_create(b"\0" * 128, 128, 2, 2, ctypes.byref(out)) < 0      # rank outside [0, nranks)
+    assert _lib.lib().pfa_comm_unique_id(None, 128) < 0
+    assert _lib.lib().pfa_allreduce(None, None, 16, _lib.F32, None) < 0
+    assert _lib.lib().pfa_comm_size(None) == 0 and _lib.lib().pfa_comm_rank(None) == -1
+    assert _lib.lib().pfa_comm_destroy(None) == 0
 
 
 def test_struct_layout_matches_the_header():

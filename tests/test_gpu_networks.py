@@ -404,6 +404,75 @@ def test_data_parallel_code_path_single_rank_rccl(golden):
         dist.destroy_process_group()
 
 
+def test_library_communicator_single_rank(golden):
+    """The exchange step behind the C boundary (pfa_comm_* / pfa_allreduce, include/pfa_hip.h) on the one rank a one-GPU
+    box can hold: RCCL is found and bound, a communicator comes up, float32 and bfloat16 ranges are reduced in place on the
+    calling stream (one rank: the sum is the range itself), a launch list holds the call, and GanTrainer(collectives="c") -
+    every gradient range of the step through pfa_allreduce on the stream that produced it, eagerly and with the step's
+    segments replayed as launch lists - reproduces the single-process goldens.  More than one rank is unmeasured here."""
+    import os
+    import torch.distributed as dist
+    from pfa_gan import kernels as K
+    comm = pfa_gan.Comm.create(pfa_gan.Comm.unique_id(), 1, 0)
+    assert _lib.lib().pfa_comm_size(comm.handle) == 1 and _lib.lib().pfa_comm_rank(comm.handle) == 0
+    x = torch.randn(100003, device="cuda")
+    xb = torch.randn(4099, device="cuda").to(torch.bfloat16)
+    x0, xb0 = x.clone(), xb.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.allreduce(x)
+        comm.allreduce(xb)
+        comm.allreduce(x[:0])                      # an empty range is no call at all
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0) and torch.equal(xb, xb0)
+    with pytest.raises(_lib.PfaError, match="contiguous"):
+        comm.allreduce(x[::2])
+    with pytest.raises(TypeError):
+        comm.allreduce(x.double())
+    y = torch.zeros_like(x)
+    with _lib.Recorder() as rec:
+        K.axpy(y, x, 1.0)
+        comm.allreduce(y)
+    ll = rec.finish()
+    assert ll.calls == 2
+    ll.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, 2 * x)
+    comm.close()
+    comm.close()                                   # idempotent
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 1000)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        name, nd, ngf, ndf, n, h, steps = STEP_CASES[0]
+        z = golden("step")
+        seed = int(z[f"step.{name}.seed"])
+        for use_graph in (False, "replay"):
+            G = pfa_gan.UNetGenerator(3, 3, num_downs=nd, ngf=ngf).cuda()
+            D = pfa_gan.NLayerDiscriminator(6, ndf=ndf).cuda()
+            load(G, fill.fill_state(nets.g_state_shapes(3, 3, nd, ngf), seed=5, bn_noise=False))
+            load(D, fill.fill_state(nets.d_state_shapes(6, ndf, 3), seed=6, bn_noise=False))
+            tr = pfa_gan.GanTrainer(G, D, precision="fp32", process_group=dist.group.WORLD, collectives="c",
+                                    use_graph=use_graph)
+            assert tr.ccomm is not None and tr.ccomm.nranks == 1
+            calls = []
+            inner = tr.ccomm.allreduce
+            tr.ccomm.allreduce = lambda t: (calls.append(t.numel()), inner(t))[1]
+            for i in range(steps):
+                a = torch.from_numpy(fill.uniform(f"step.{name}.a{i}", (n, 3, h, h), seed=seed)).cuda()
+                b = torch.from_numpy(fill.uniform(f"step.{name}.b{i}", (n, 3, h, h), seed=seed)).cuda()
+                losses = tr.step(a, b).cpu().numpy()
+                assert_close(losses[0], z[f"step.{name}.loss_d{i}"], 1e-4, 1e-4, f"loss_d step {i}")
+                assert_close(losses[1], z[f"step.{name}.loss_g{i}"], 1e-3, 1e-4, f"loss_g step {i}")
+            _check_step_state(z, name, G, D)
+            assert sum(calls) >= steps * (tr.G.flat.total + tr.Dn.flat.total), "every gradient range went through pfa_allreduce"
+            tr.ccomm.close()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("mode", ["three-streams", "one-stream", "resident-inputs", "bf16-payload"])
 def test_data_parallel_stream_order_under_a_slow_collective(monkeypatch, mode):
     """What neither gloo (host-blocking waits) nor a 1-rank RCCL group (an all-reduce that changes nothing) can show: that
