@@ -538,6 +538,10 @@ def main():
         torch.cuda.synchronize()
 
     launches0 = _lib.launch_count()
+    if os.environ.get("PFA_MAIN_HIGH"):              # A/B switch: the step's main stream at high priority (side streams: normal)
+        hp = torch.cuda.Stream(priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for i in range(args.warmup):
         trainer.step_packed(*pool[i % len(pool)])
     reps = []

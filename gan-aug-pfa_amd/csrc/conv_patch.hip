@@ -444,38 +444,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
     const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
-    const char* zero = (const char*)g_pfa_zero_page;
-
-    unsigned poff[PPASS];
-    unsigned pok = 0;
-#pragma unroll
-    for (int j = 0; j < PPASS; ++j) {
-        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
-        const int py = slot / PW, px = slot - py * PW;
-        const int iy = oy0 - q.org + py, ix = ox0 - q.org + px;
-        const bool ok = g < 8 && slot < PSLOTS && (unsigned)iy < (unsigned)q.hin && (unsigned)ix < (unsigned)q.win;
-        poff[j] = ok ? (unsigned)((((img * q.hin + iy) * q.win + ix) * q.cin + g * 8) * 2) : 0u;
-        pok |= ok ? (1u << j) : 0u;
-    }
     const int c0 = split * q.cper;
-    auto stage_patch_piece = [&](int chunk, int j) {
-        const char* gp = ((pok >> j) & 1u) ? p.src1 + poff[j] + (c0 + chunk) * 128 : zero;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * PATCH_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
-    };
+    const int nsteps = q.cper * 16;
+
+    // All DMA in the buffer form of pfa_common.h (buf_dma16): per-lane offsets fixed for the whole loop, the channel chunk
+    // (and the tap, for the weights) in ONE scalar per piece; PFA_DMA_OOB where the hardware is to write zeros - out-of-image
+    // pixels, the padding piece, and every piece of a chunk behind the slice's last one (those are still issued: all steps
+    // issue and wait alike).  Weights first: their latency runs under the patch's address arithmetic.
     const int cs = tid & 7, r0 = tid >> 3;
     const int wg = cs ^ ((r0 >> 1) & 7);
     unsigned woff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
-    auto stage_w = [&](int step, unsigned slot_off) {         // step = chunk * 16 + tap position
-        const int chunk = c0 + (step >> 4), tap = q.flip ? 15 - (step & 15) : (step & 15);
+    const unsigned cin2 = (unsigned)q.cin * 2;
+    const unsigned tap0 = q.flip ? 15u * cin2 : 0u;              // tap of position V: flip ? 15 - V : V
+    const int tapd = q.flip ? -(int)cin2 : (int)cin2;
+    auto stage_w = [&](unsigned chunk_off, auto v_, unsigned slot_off) {         // tap position V of the chunk with scalar chunk_off
+        constexpr int V = decltype(v_)::value;
         char* wb = smem + 2 * PATCH_BYTES + slot_off;
+        const unsigned soff = chunk_off + (unsigned)((int)tap0 + V * tapd);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const char* gp = p.w + woff[i] + (tap * q.cin + chunk * 64) * 2;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i) buf_dma16(p.w, wb + (i * 512 + wave * 64) * 16, woff[i], soff);
     };
+    unsigned ck_cur = (unsigned)c0 * 128, ck_nxt = q.cper > 1 ? ck_cur + 128 : PFA_DMA_OOB;      // this chunk's and the next one's scalar
+    stage_w(ck_cur, std::integral_constant<int, 0>{}, 0);
+    stage_w(ck_cur, std::integral_constant<int, 1>{}, W_BYTES);
+    unsigned poff[PPASS];
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) {
+        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
+        const int py = slot / PW, px = slot - py * PW;
+        const int iy = oy0 - q.org + py, ix = ox0 - q.org + px;
+        const unsigned ok = (unsigned)(g < 8) & (unsigned)(slot < PSLOTS) & (unsigned)((unsigned)iy < (unsigned)q.hin) & (unsigned)((unsigned)ix < (unsigned)q.win);
+        const unsigned keep = 0u - ok;
+        poff[j] = ((unsigned)((((img * q.hin + iy) * q.win + ix) * q.cin + g * 8) * 2) & keep) | (PFA_DMA_OOB & ~keep);
+    }
+    auto stage_patch_piece = [&](unsigned chunk_off, int buf, int j) {
+        buf_dma16(p.src1, smem + buf * PATCH_BYTES + (j * 512 + wave * 64) * 16, poff[j], chunk_off);
+    };
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) stage_patch_piece(ck_cur, 0, j);
 
     f32x16 acc[FN][FM];
 #pragma unroll
@@ -508,20 +516,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int b = 0; b < FM; ++b) fa[b][s2] = bf16x8{};
     }
-    // reads of k-step S2 of the step at tap position V: weight addresses wv[] (slot already added), activation bases ab[]
+    // fragment E (0, 1: weight tiles; 2, 3: activation tiles) of k-step S2 of the step at tap position V: weight addresses wv[]
+    // (slot already added), activation bases ab[]
+    auto read_frag = [&](auto v_, auto s2_, auto e_, const unsigned (&ab)[FM], const unsigned (&wv)[KS]) {
+        constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value, E = decltype(e_)::value;
+        if constexpr (E == 0) s1_rd<0>(wv[S2], fw[0][S2]);
+        else if constexpr (E == 1) s1_rd<4096>(wv[S2], fw[1][S2]);
+        else s1_rd<s1_tap_off(V) + S2 * 32>(ab[E - 2], fa[E - 2][S2]);
+    };
     auto read_kstep = [&](auto v_, auto s2_, const unsigned (&ab)[FM], const unsigned (&wv)[KS]) {
-        constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value;
-        s1_rd<0>(wv[S2], fw[0][S2]);
-        s1_rd<4096>(wv[S2], fw[1][S2]);
-#pragma unroll
-        for (int b = 0; b < FM; ++b) s1_rd<s1_tap_off(V) + S2 * 32>(ab[b], fa[b][S2]);
+        read_frag(v_, s2_, std::integral_constant<int, 0>{}, ab, wv);
+        read_frag(v_, s2_, std::integral_constant<int, 1>{}, ab, wv);
+        read_frag(v_, s2_, std::integral_constant<int, 2>{}, ab, wv);
+        read_frag(v_, s2_, std::integral_constant<int, 3>{}, ab, wv);
     };
 
-    const int nsteps = q.cper * 16;
-#pragma unroll
-    for (int j = 0; j < PPASS; ++j) stage_patch_piece(0, j);
-    stage_w(0, 0);
-    stage_w(1, W_BYTES);
     wait_vmc<0>();
     __builtin_amdgcn_s_barrier();
     unsigned acur[FM] = {abuf[0][0], abuf[0][1]}, aoth[FM] = {abuf[1][0], abuf[1][1]};
@@ -537,13 +546,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, acur, wv);
     }
 
-    auto body = [&](int i, auto v_, const bool more) {
+    // step at tap position V of chunk `chunk` (patch buffer chunk & 1); more: a step follows
+    auto body = [&](int chunk, auto v_, const bool more) {
         constexpr int V = decltype(v_)::value, NV = (V + 1) & 15;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int chunk = i >> 4;
-        const bool w_issued = i + 2 < nsteps;
-        const bool p_issued = V < PPASS && chunk + 1 < q.cper;
+        constexpr bool p_issued = V < PPASS;
         unsigned wv[KS];                                     // the next step's weight fragment addresses
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) wv[s2] = wadr[s2] + w_nxt;
@@ -555,36 +563,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int b = 0; b < FM; ++b) pin(fa[b][S2]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < FN; ++a)
-#pragma unroll
-                for (int b = 0; b < FM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a][S2], fa[b][S2], acc[a][b], 0, 0, 0);
+            // the k-step's reads and DMA in the shadows of its own MFMAs (see conv_patch2.hip): M(w0,a0) [DMA] M(w1,a0) R(a0)
+            // M(w0,a1) R(w0) M(w1,a1) R(w1) R(a1)
+            auto mfma = [&](auto a_, auto b_) {
+                constexpr int A = decltype(a_)::value, B = decltype(b_)::value;
+                acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[A][S2], fa[B][S2], acc[A][B], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rd = [&](auto e_) {
+                if (more) {
+                    if (V == 15) read_frag(std::integral_constant<int, NV>{}, s2_, e_, aoth, wv);
+                    else read_frag(std::integral_constant<int, NV>{}, s2_, e_, acur, wv);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            mfma(I0{}, I0{});
+            if (S2 == 0) stage_w(V + 2 < 16 ? ck_cur : ck_nxt, std::integral_constant<int, (V + 2) & 15>{}, w_fil);       // stage i+2
+            if (S2 == 2 && p_issued) stage_patch_piece(ck_nxt, (chunk + 1) & 1, V < PPASS ? V : 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                if (V == 15) read_kstep(std::integral_constant<int, NV>{}, s2_, aoth, wv);
-                else read_kstep(std::integral_constant<int, NV>{}, s2_, acur, wv);
-            }
-            if (S2 == 0 && w_issued) stage_w(i + 2, w_fil);
-            if (S2 == 2 && p_issued) stage_patch_piece(chunk + 1, V < PPASS ? V : 0);
-            __builtin_amdgcn_sched_barrier(0);
+            mfma(I1{}, I0{}); rd(I2{}); mfma(I0{}, I1{}); rd(I0{}); mfma(I1{}, I1{}); rd(I1{}); rd(I3{});
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
         // stage i+2 (issued at k-step 0) has landed; a patch piece issued behind it may stay in flight
-        if (p_issued) wait_vmc<1>(); else wait_vmc<0>();
+        wait_vmc<p_issued ? 1 : 0>();
         const unsigned t = w_cur; w_cur = w_nxt; w_nxt = w_fil; w_fil = t;
     };
-    for (int i = 0; i < nsteps; i += 16) {
-        const bool next = i + 16 < nsteps;
+    for (int chunk = 0; chunk < q.cper; ++chunk) {
+        const bool next = chunk + 1 < q.cper;
         [&]<int... V>(std::integer_sequence<int, V...>) {
-            (body(i + V, std::integral_constant<int, V>{}, V < 15 || next), ...);
+            (body(chunk, std::integral_constant<int, V>{}, V < 15 || next), ...);
         }(std::make_integer_sequence<int, 16>{});
 #pragma unroll
         for (int b = 0; b < FM; ++b) { const unsigned t = acur[b]; acur[b] = aoth[b]; aoth[b] = t; }
+        ck_cur = ck_nxt;
+        ck_nxt = chunk + 2 < q.cper ? ck_cur + 128 : PFA_DMA_OOB;
     }
+    wait_vmc<0>();                               // (the pieces issued behind the slice's end)
 
     constexpr int RS = patch_image_stride<128>();
     __syncthreads();
@@ -648,6 +667,8 @@ int pfa_conv_s1_patch(int grad, const void* src, const void* w, void* out, float
 bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int splitk_caller, int* bn, int* splitk, int* stat_tiles) {
     const int hout = grad ? hin + 1 : hin - 1, wout = grad ? win + 1 : win - 1;
     if (cin % 64 || n % 64 || hout < 1 || wout < 1) return false;
+    // (buffer-form LDS-DMA: every in-range offset stays below 2 GiB)
+    if ((long long)nb * hin * win * cin * 2 >= (1LL << 31) || (long long)n * 16 * cin * 2 >= (1LL << 31)) return false;
     const int tiles = nb * ((hout + TY - 1) / TY) * ((wout + TX - 1) / TX);
     int b = 0, sk = 1;
     // (knob 10: the threshold, 128.  c4's input gradient then runs un-sliced on 128 workgroups with the fused BatchNorm

@@ -98,79 +98,120 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
     const int py = cls >> 1, px = cls & 1;
     const int qy0 = ty * TY, qx0 = tx * TX, n0 = nt * BN;
-    const char* zero = (const char*)g_pfa_zero_page;
     auto stamp = [&](int k) {          // shader clock at four points of the workgroup's life (a separate measurement, never a result)
         if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 16 + k] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     if (q.stamps && tid == 0) q.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();     // 100 MHz, chip-wide
 
-    // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding
-    int ppix[PPASS];             // source pixel * 8 + piece (MODE 1: of plane (0,0); plane (ey,ex) adds (ey*ws + ex) * 8)
-    unsigned pok = 0;            // validity bits: MODE 0 bit j; MODE 1 bit plane*8 + j
-#pragma unroll
-    for (int j = 0; j < PPASS; ++j) {
-        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
-        const int sy = slot / PW, sx = slot - sy * PW;
-        const bool inb = g < 8 && slot < PSLOTS;
-        if (MODE == 0) {
-            const int iy = qy0 + py - 1 + sy, ix = qx0 + px - 1 + sx;
-            const bool ok = inb && (unsigned)iy < (unsigned)p.hs && (unsigned)ix < (unsigned)p.ws;
-            ppix[j] = ((img * p.hs + iy) * p.ws + ix) * 8 + (g & 7);
-            pok |= ok ? (1u << j) : 0u;
-        } else {
-            const int iy = 2 * (qy0 + sy) - 1, ix = 2 * (qx0 + sx) - 1;
-            ppix[j] = ((img * p.hs + iy) * p.ws + ix) * 8 + (g & 7);
-#pragma unroll
-            for (int pl = 0; pl < 4; ++pl) {
-                const int y = iy + (pl >> 1), x = ix + (pl & 1);
-                const bool ok = inb && (unsigned)y < (unsigned)p.hs && (unsigned)x < (unsigned)p.ws;
-                pok |= ok ? (1u << (pl * 8 + j)) : 0u;
-            }
-        }
-    }
+    constexpr bool no_mfma = ABL & 1, no_read = ABL & 2, no_dma = ABL & 4, no_vmwait = ABL & 8, no_barrier = ABL & 16;
     const int ss0 = split * q.ssper;
     const int nss = min(q.nss, ss0 + q.ssper) - ss0;          // super-steps of this slice
     const int nsteps = nss * 4;
-    // super-step S of the slice -> (source, channel chunk, plane)
-    auto stage_patch = [&](int S, int j0, int j1) {
-        const int gs = ss0 + S;
-        const int chunk = MODE == 0 ? gs : gs >> 2, pl = MODE == 0 ? 0 : gs & 3;
-        const bool first = chunk < q.c1chunks;
-        const char* base = first ? p.src1 : p.src2;
-        const int C = first ? p.c1 : p.c2, cc = first ? chunk : chunk - q.c1chunks;
-        const int c8 = C >> 3;                               // 16-byte pieces per pixel
-        const int pladd = MODE == 0 ? 0 : ((pl >> 1) * p.ws + (pl & 1)) * 8;
-        char* dst = smem + (S & 1) * PATCH_BYTES;
-#pragma unroll
-        for (int j = j0; j < j1; ++j) {
-            const bool ok = (pok >> ((MODE == 0 ? 0 : pl * 8) + j)) & 1u;
-            const int pg = ppix[j] + pladd;                  // pixel * 8 + piece
-            const int pix = pg >> 3, g = pg & 7;
-            const unsigned off = (unsigned)((pix * c8 * 8 + cc * 64 + g * 8) * 2);
-            const char* gp = ok ? base + off : zero;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(dst + (j * 512 + wave * 64) * 16), 16, 0, 0);
-        }
-    };
-    // ---- weight staging: WP pieces per step (rows r0 + 64 i of the tile), chunk slot cs holds source chunk cs ^ swz(row)
+    const unsigned C2 = (unsigned)p.c1 * 2, C2b = (unsigned)p.c2 * 2;        // bytes per pixel of the two sources
+    const unsigned ctot2 = (unsigned)p.ctot * 2;
+    // All DMA is the buffer form of pfa_common.h (buf_dma16): a per-lane offset that is fixed for the whole K loop plus ONE
+    // scalar per piece for what changes from step to step; a lane that is to read zeros carries PFA_DMA_OOB.
+    // A super-step (S) behind the slice's last one gets out-of-range scalars: its pieces are still issued (zeros into ring
+    // slots and a patch buffer nobody reads, no memory traffic), so every step issues the same pieces and waits with the same
+    // counted vmcnt - no conditions in the loop.
+    // ---- weight staging: WP pieces per step (rows r0 + 64 i of the tile), chunk slot cs holds source chunk cs ^ swz(row).
+    // Scalar: super-step's share (channel chunk; MODE 1: the plane's part of the tap index) + the tap's share, one of four
+    // per-workgroup constants.  Issued FIRST: the first stages' latency runs under the patch's address arithmetic below.
     const int cs = tid & 7, r0 = tid >> 3;
     const int wgc = cs ^ ((r0 >> 1) & 7);
     unsigned woff[WP];
 #pragma unroll
     for (int i = 0; i < WP; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * p.ctot + wgc * 8) * 2);
-    auto stage_w_piece = [&](int step, int i) {               // step of this slice: super-step step >> 2, tap step & 3
-        const int gs = ss0 + (step >> 2), t = step & 3, a = t >> 1, b = t & 1;
-        int chunk, widx;
-        if (MODE == 0) { chunk = gs; widx = (3 - py - 2 * a) * 4 + (3 - px - 2 * b); }
-        else { chunk = gs >> 2; const int pl = gs & 3; widx = (2 * a + (pl >> 1)) * 4 + 2 * b + (pl & 1); }
-        char* wb = smem + WBASE + (step & (W_SLOTS - 1)) * W_BYTES;
-        const char* gp = p.w + woff[i] + (unsigned)((widx * p.ctot + chunk * 64) * 2);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(wb + (i * 512 + wave * 64) * 16), 16, 0, 0);
-    };
-    auto stage_w = [&](int step) {
+    unsigned wtap[4];            // tap t = (a, b): MODE 0 tap index (3 - py - 2a) * 4 + (3 - px - 2b), MODE 1 (2a) * 4 + 2b (+ the plane's part)
 #pragma unroll
-        for (int i = 0; i < WP; ++i) stage_w_piece(step, i);
+    for (int t = 0; t < 4; ++t) {
+        const int a = t >> 1, b = t & 1;
+        wtap[t] = (unsigned)(MODE == 0 ? (3 - py - 2 * a) * 4 + (3 - px - 2 * b) : 8 * a + 2 * b) * ctot2;
+    }
+    auto wsoff_of = [&](int S) -> unsigned {
+        const int gs = ss0 + S;
+        const int chunk = MODE == 0 ? gs : gs >> 2, pl = MODE == 0 ? 0 : gs & 3;
+        return S < nss ? (unsigned)chunk * 128 + (MODE == 0 ? 0u : (unsigned)((pl >> 1) * 4 + (pl & 1)) * ctot2) : PFA_DMA_OOB;
     };
+    auto stage_w_piece = [&](unsigned wsoff, auto t_, int i) {  // tap t (= weight slot) of the super-step with scalar wsoff, piece i
+        constexpr int TP = decltype(t_)::value;
+        char* wb = smem + WBASE + TP * W_BYTES;
+        buf_dma16(p.w, wb + (i * 512 + wave * 64) * 16, woff[i], wsoff + wtap[TP]);
+    };
+    if (!no_dma) {               // steps 0 .. 2 (a slice has at least one super-step = 4 steps)
+        const unsigned w0 = wsoff_of(0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i) {
+            stage_w_piece(w0, std::integral_constant<int, 0>{}, i);
+            stage_w_piece(w0, std::integral_constant<int, 1>{}, i);
+            stage_w_piece(w0, std::integral_constant<int, 2>{}, i);
+        }
+    }
+    // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding.
+    // pvoff[j]: the lane's byte offset inside the source tensor - pixel * pixel pitch + 16 g - fixed while the K loop walks
+    // one source (pvoff2: the same for the second source's pitch, copied over pvoff when the walk gets there).  Scalar: the
+    // channel chunk and, MODE 1, the parity plane.  MODE 1: pvoff is the plane-(0,0) pixel moved down-right by one row and one
+    // pixel, and the source base is moved back by as much: the offsets of pixels that exist in SOME plane are then never
+    // negative.  pok: validity bit plane * 8 + j.
+    unsigned pvoff[PPASS], pvoff2[PPASS];
+    unsigned pok = 0;
+#pragma unroll
+    for (int j = 0; j < PPASS; ++j) {
+        const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
+        const int sy = slot / PW, sx = slot - sy * PW;
+        const bool inb = g < 8 && slot < PSLOTS;
+        unsigned pix, any;               // (validity as 0 / 1 integers and bitwise operators: `&&` / `||` / `?:` on per-lane
+                                         //  conditions compile to exec-masked branches, two dozen of them in this prologue)
+        if (MODE == 0) {
+            const int iy = qy0 + py - 1 + sy, ix = qx0 + px - 1 + sx;
+            any = (unsigned)inb & (unsigned)((unsigned)iy < (unsigned)p.hs) & (unsigned)((unsigned)ix < (unsigned)p.ws);
+            pix = (unsigned)((img * p.hs + iy) * p.ws + ix);
+        } else {
+            const int iy = 2 * (qy0 + sy) - 1, ix = 2 * (qx0 + sx) - 1;
+            const unsigned y0 = (unsigned)((unsigned)iy < (unsigned)p.hs), y1 = (unsigned)((unsigned)(iy + 1) < (unsigned)p.hs);
+            const unsigned x0 = (unsigned)((unsigned)ix < (unsigned)p.ws), x1 = (unsigned)((unsigned)(ix + 1) < (unsigned)p.ws);
+            const unsigned in1 = (unsigned)inb;
+            const unsigned b4 = (0u - in1) & ((y0 & x0) | ((y0 & x1) << 8) | ((y1 & x0) << 16) | ((y1 & x1) << 24));     // plane (ey, ex) -> bit 8 (2 ey + ex)
+            pok |= b4 << j;
+            any = b4 != 0u;
+            pix = (unsigned)((img * p.hs + iy + 1) * p.ws + ix + 1);
+        }
+        const unsigned keep = 0u - any;          // all ones where the lane reads pixels in some step
+        pvoff[j] = ((pix * C2 + (unsigned)g * 16) & keep) | (PFA_DMA_OOB & ~keep);
+        pvoff2[j] = ((pix * C2b + (unsigned)g * 16) & keep) | (PFA_DMA_OOB & ~keep);
+    }
+    const char* const src1s = MODE == 0 ? p.src1 : p.src1 - (size_t)(p.ws + 1) * C2;
+    const char* const src2s = MODE == 0 ? p.src2 : p.src2 - (size_t)(p.ws + 1) * C2b;
+    // What changes from super-step to super-step is formed ONCE per super-step (SS).  Inside a step a DMA piece then costs
+    // its M0 move, MODE 1 one select on the per-lane offset, and the instruction itself.
+    struct SS { unsigned wsoff; const char* pbase; unsigned psoff; unsigned bits; };
+    auto make_ss = [&](int S) -> SS {                        // super-step S of this slice
+        const int gs = ss0 + S;
+        const int chunk = MODE == 0 ? gs : gs >> 2, pl = MODE == 0 ? 0 : gs & 3;
+        const bool first = chunk < q.c1chunks;
+        const int cc = first ? chunk : chunk - q.c1chunks;
+        SS r;
+        r.wsoff = wsoff_of(S);
+        r.pbase = first ? src1s : src2s;
+        r.psoff = S < nss ? (unsigned)cc * 128 + (MODE == 0 ? 0u : (unsigned)((pl >> 1) * p.ws + (pl & 1)) * (first ? C2 : C2b)) : PFA_DMA_OOB;
+        if (!first) {            // the walk is in the second source (every piece of the first one has been issued)
+#pragma unroll
+            for (int j = 0; j < PPASS; ++j) pvoff[j] = pvoff2[j];
+        }
+        r.bits = MODE == 0 ? 0u : pok >> (pl * 8);
+        return r;
+    };
+    auto stage_patch = [&](const SS& ss, int buf, int j0, int j1) {      // pieces j0 .. j1-1 into patch buffer buf
+        char* dst = smem + buf * PATCH_BYTES;
+#pragma unroll
+        for (int j = j0; j < j1; ++j) {
+            const unsigned v = MODE == 0 ? pvoff[j] : (((ss.bits >> j) & 1u) ? pvoff[j] : PFA_DMA_OOB);
+            buf_dma16(ss.pbase, dst + (j * 512 + wave * 64) * 16, v, ss.psoff);
+        }
+    };
+    SS cur = make_ss(0), nxt = cur;              // the super-step of the running step and the one behind it
+    if (!no_dma) stage_patch(cur, 0, 0, PPASS);
 
     f32x16 acc[FN][FM];
 #pragma unroll
@@ -227,15 +268,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         }(std::make_integer_sequence<int, NREAD>{});
     };
 
-    // ---- prologue: patch 0, weight stages 0..2, the first two pieces of patch 1
-    constexpr bool no_mfma = ABL & 1, no_read = ABL & 2, no_dma = ABL & 4;
+    // ---- prologue: patch 0 and the weight stages 0..2 are on their way (issued above)
     constexpr int NR = FN + FM;                  // fragment reads of one k-step
-    if (!no_dma) {
-        stage_patch(0, 0, PPASS);
-        stage_w(0);
-        if (nsteps > 1) stage_w(1);
-        if (nsteps > 2) stage_w(2);
-    }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     Frags fr;                                    // ONE fragment set: k-step s of step i+1 is read into the registers of
@@ -256,17 +290,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     auto body = [&](int i, auto v_, const bool more) {
         constexpr int V = decltype(v_)::value;
         constexpr int NV = (V + 1) & 7;                       // the next step's combination
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // DMA of this step: up to WP weight pieces (stage i+3) and three pieces of the next super-step's patch
-        const bool w_issued = !no_dma && i + 3 < nsteps;
         constexpr int rel = V & 3;
-        const int pS = (i >> 2) + 1;
+        if constexpr (rel == 0) { cur = nxt; nxt = make_ss((i >> 2) + 1); }     // (before the barrier: scalar work, nothing waits for it)
+        if (!no_barrier) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // DMA of this step: the WP weight pieces of stage i+3 and, in the first two steps of a super-step, three pieces each of
+        // the next super-step's patch (behind the slice's end: out-of-range offsets, see make_ss)
         constexpr int pj = rel == 0 ? 0 : 3;
-        const bool p_issued = !no_dma && rel < 2 && pS < nss;
+        constexpr bool p_issued = !no_dma && rel < 2;
         auto dma_op = [&](int k) {               // op k of this step's list: W pieces first, then the three patch pieces
-            if (k < WP) { if (w_issued) stage_w_piece(i + 3, k); }
-            else if (p_issued) stage_patch(pS, pj + (k - WP), pj + (k - WP) + 1);
+            if (k < WP) { if (!no_dma) stage_w_piece(rel == 0 ? cur.wsoff : nxt.wsoff, std::integral_constant<int, (V + 3) & 3>{}, k); }
+            else if (p_issued) stage_patch(nxt, ((V >> 2) + 1) & 1, pj + (k - WP), pj + (k - WP) + 1);
         };
         constexpr int NOPS = WP + 3;
         auto kstep = [&](auto s2_) {
@@ -280,36 +314,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 for (int b = 0; b < FM; ++b) pin(fr.a[b][S2]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!no_mfma) {
+            // The k-step's other instructions sit in the shadows of its own MFMAs (a wave issues in order: behind four MFMAs
+            // in a row they would all wait for the matrix pipe to drain first).  Order: M(w0,a0) [DMA] M(w1,a0) R(a0) M(w0,a1)
+            // R(w0) M(w1,a1) R(w1) R(a1) - a fragment of the NEXT step is read into its registers as soon as the last MFMA
+            // that takes the old value has been issued.  knob 14 = 1 (diagnostic instantiation INTER = 0): the old order.
+            auto mfma = [&](auto a_, auto b_) {
+                constexpr int A = decltype(a_)::value, B = decltype(b_)::value;
+                if (!no_mfma) acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.w[A][S2], fr.a[B][S2], acc[A][B], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto rd = [&](auto e_) {             // fragment e (0 .. FN-1: weights, FN ..: activations) of this k-step, next tap step
+                constexpr int E = decltype(e_)::value;
+                if (!no_read && more)
+                    read_one(fr, std::integral_constant<int, (NV >> 2) & 1>{}, std::integral_constant<int, NV & 3>{},
+                             std::integral_constant<int, NV & 3>{}, std::integral_constant<int, S2 * NR + E>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto dma = [&]() {
 #pragma unroll
-                for (int a = 0; a < FN; ++a)
-#pragma unroll
-                    for (int b = 0; b < FM; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.w[a][S2], fr.a[b][S2], acc[a][b], 0, 0, 0);
+                for (int k = 0; k < NOPS; ++k)
+                    if (S2 == (k * KS) / NOPS) dma_op(k);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            if constexpr (FN == 2) {
+                mfma(I0{}, I0{}); dma(); mfma(I1{}, I0{}); rd(I2{}); mfma(I0{}, I1{}); rd(I0{}); mfma(I1{}, I1{}); rd(I1{}); rd(I3{});
+            } else {
+                mfma(I0{}, I0{}); dma(); rd(I1{}); mfma(I0{}, I1{}); rd(I0{}); rd(I2{});
             }
-            __builtin_amdgcn_sched_barrier(0);
-            // the same k-step of the next tap step, into the registers just consumed
-            if (!no_read && more) {
-                [&]<int... R>(std::integer_sequence<int, R...>) {
-                    (read_one(fr, std::integral_constant<int, (NV >> 2) & 1>{}, std::integral_constant<int, NV & 3>{},
-                              std::integral_constant<int, NV & 3>{}, std::integral_constant<int, S2 * NR + R>{}), ...);
-                }(std::make_integer_sequence<int, NR>{});
-            }
-            // this step's DMA ops, spread over the k-steps
-#pragma unroll
-            for (int k = 0; k < NOPS; ++k)
-                if (S2 == (k * KS) / NOPS) dma_op(k);
-            __builtin_amdgcn_sched_barrier(0);
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
         static_assert(KS == 4, "k-steps of a tap step");
-        if (w_issued && p_issued) wait_vm<WP + 3>();
-        else if (w_issued) wait_vm<WP>();
-        else if (p_issued) wait_vm<3>();
-        else wait_vm<0>();
+        if (no_dma) wait_vm<0>();
+        else if (!no_vmwait) wait_vm<p_issued ? WP + 3 : WP>();
     };
     // Each step body exists ONCE (duplicated tail copies cost registers, and a spilled fragment register would be saved
     // before its in-flight LDS read has landed): `more` is a run-time flag only in the last step of a super-step.
@@ -321,6 +362,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         PFA_STEP(4, true); PFA_STEP(5, true); PFA_STEP(6, true); PFA_STEP(7, i + 8 < nsteps);
     }
 #undef PFA_STEP
+    wait_vm<0>();                                // (the pieces issued behind the slice's end land before the buffers are reused)
     stamp(2);
 
     // ---- epilogue: accumulators -> fp32 [position][channel] image in LDS -> whole NHWC rows out (patch_epilogue.h).
@@ -380,6 +422,9 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
     if (dtype != PFA_BF16 || !(k.mode == PFA_TCONV_S2 || k.mode == PFA_CONV_S2) || !k.small32) return false;
     if (k.c1 % 64 || k.c2 % 64 || k.n % 64 || k.act == PFA_ACT_TANH) return false;
     if (k.hq < 8 || k.wq < 16) return false;
+    // buffer-form LDS-DMA: every in-range offset stays below 2 GiB
+    if (((long long)k.nb * k.hs * k.ws + k.ws + 2) * (k.c1 > k.c2 ? k.c1 : k.c2) * 2 >= (1LL << 31) || (long long)k.n * 16 * k.ctot * 2 >= (1LL << 31))
+        return false;
     Patch2Plan pl{};
     pl.tile16 = k.wq < 32 ? 1 : 0;
     const int tyy = pl.tile16 ? 16 : 8, txx = pl.tile16 ? 16 : 32;
@@ -429,6 +474,8 @@ int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, co
                                    "k_conv_patch2<tconv,64,16x16>", "k_conv_patch2<conv_s2,128,8x32>", "k_conv_patch2<conv_s2,128,16x16>",
                                    "k_conv_patch2<conv_s2,64,8x32>", "k_conv_patch2<conv_s2,64,16x16>"};
     if (kernel_name) *kernel_name = names[sel];
+    if (sel == 4 && pfa_knob(7) == 18) return launch_patch2<1, 128, 0, 8>(q, st);       // no counted vmcnt wait in the loop (races: timing only)
+    if (sel == 4 && pfa_knob(7) == 19) return launch_patch2<1, 128, 0, 24>(q, st);      // nor the step's barrier
     if (sel == 4 && pfa_knob(7) >= 11 && pfa_knob(7) <= 17) {      // developer ablations of the stride-2 128-channel kernel (results are wrong)
         switch (pfa_knob(7) - 10) {
             case 1: return launch_patch2<1, 128, 0, 1>(q, st);     // no MFMA

@@ -65,39 +65,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
     const int qy0 = ty * T4_TY, qx0 = tx * T4_TX, n0 = nt * T4_BN;
-    const char* zero = (const char*)g_pfa_zero_page;
-
-    // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding
-    int ppix[T4_PPASS];
-    unsigned pok = 0;
+    const int nsteps = q.nchunks * 16;
+    // All DMA in the buffer form of pfa_common.h (buf_dma16): per-lane offsets fixed for the whole loop, the channel chunk (and
+    // the tap, for the weights) in ONE scalar per piece, PFA_DMA_OOB where the hardware is to write zeros - out-of-image
+    // pixels, the padding piece, every piece of a chunk behind the last one (still issued: all steps issue and wait alike).
+    // ---- weight staging: one piece per lane and step: row r0 of the tile, chunk slot cs holds source chunk cs ^ swz(row).
+    // Issued first: the latency of stages 0..2 runs under the patch's address arithmetic.
+    const int cs = tid & 7, r0 = tid >> 3;
+    const unsigned woff = (unsigned)(((n0 + r0) * 16 * p.ctot + (cs ^ ((r0 >> 1) & 7)) * 8) * 2);
+    const unsigned ctot2 = (unsigned)p.ctot * 2;
+    auto stage_w = [&](unsigned chunk_off, auto v_) {         // (class, tap) = V of the chunk with scalar chunk_off (chunk * 128, or out of range)
+        constexpr int V = decltype(v_)::value;
+        buf_dma16(p.w, smem + T4_WBASE + (V & (T4_WSLOTS - 1)) * T4_WBYTES + wave * 1024, woff, chunk_off + (unsigned)t4_widx(V) * ctot2);
+    };
+    stage_w(0u, std::integral_constant<int, 0>{}); stage_w(0u, std::integral_constant<int, 1>{}); stage_w(0u, std::integral_constant<int, 2>{});
+    // ---- patch staging: lane's piece j = (pixel slot, 16-byte piece g of its 128 bytes); the ninth piece is padding.  pvoff:
+    // pixel * pixel pitch + 16 g for the source the loop is walking (pvoff2: for the second source's pitch, copied over when the
+    // walk gets there)
+    const unsigned C2 = (unsigned)p.c1 * 2, C2b = (unsigned)p.c2 * 2;
+    unsigned pvoff[T4_PPASS], pvoff2[T4_PPASS];
 #pragma unroll
     for (int j = 0; j < T4_PPASS; ++j) {
         const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
         const int sy = slot / T4_PW, sx = slot - sy * T4_PW;
         const int iy = qy0 - 1 + sy, ix = qx0 - 1 + sx;
-        const bool ok = g < 8 && slot < T4_SLOTS && (unsigned)iy < (unsigned)p.hs && (unsigned)ix < (unsigned)p.ws;
-        ppix[j] = ((img * p.hs + iy) * p.ws + ix) * 8 + (g & 7);
-        pok |= ok ? (1u << j) : 0u;
+        const unsigned ok = (unsigned)(g < 8) & (unsigned)(slot < T4_SLOTS) & (unsigned)((unsigned)iy < (unsigned)p.hs) & (unsigned)((unsigned)ix < (unsigned)p.ws);
+        const unsigned keep = 0u - ok, pix = (unsigned)((img * p.hs + iy) * p.ws + ix);
+        pvoff[j] = ((pix * C2 + (unsigned)g * 16) & keep) | (PFA_DMA_OOB & ~keep);
+        pvoff2[j] = ((pix * C2b + (unsigned)g * 16) & keep) | (PFA_DMA_OOB & ~keep);
     }
-    auto stage_patch_piece = [&](int chunk, int j) {
-        const bool first = chunk < q.c1chunks;
-        const char* base = first ? p.src1 : p.src2;
-        const int C = first ? p.c1 : p.c2, cc = first ? chunk : chunk - q.c1chunks;
-        const int pix = ppix[j] >> 3, g = ppix[j] & 7;
-        const unsigned off = (unsigned)((pix * C + cc * 64 + g * 8) * 2);
-        const char* gp = ((pok >> j) & 1u) ? base + off : zero;
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + (chunk & 1) * T4_PATCH + (j * 512 + wave * 64) * 16), 16, 0, 0);
+    // scalars of a chunk: weights chunk * 128; patch: source base and chunk-in-source * 128
+    struct CK { unsigned woff; const char* pbase; unsigned poff; };
+    auto make_ck = [&](int chunk) -> CK {
+        const bool live = chunk < q.nchunks, first = chunk < q.c1chunks;
+        CK r;
+        r.woff = live ? (unsigned)chunk * 128 : PFA_DMA_OOB;
+        r.pbase = first ? p.src1 : p.src2;
+        r.poff = live ? (unsigned)(first ? chunk : chunk - q.c1chunks) * 128 : PFA_DMA_OOB;
+        if (!first) {            // the walk is in the second source (every piece of the first one has been issued)
+#pragma unroll
+            for (int j = 0; j < T4_PPASS; ++j) pvoff[j] = pvoff2[j];
+        }
+        return r;
     };
-    // ---- weight staging: one piece per lane and step: row r0 of the tile, chunk slot cs holds source chunk cs ^ swz(row)
-    const int cs = tid & 7, r0 = tid >> 3;
-    const unsigned woff = (unsigned)(((n0 + r0) * 16 * p.ctot + (cs ^ ((r0 >> 1) & 7)) * 8) * 2);
-    auto stage_w = [&](int step) {                            // step = chunk * 16 + (class, tap)
-        const int chunk = step >> 4, v = step & 15;
-        const int py = v >> 3, px = (v >> 2) & 1, a = (v >> 1) & 1, b = v & 1;
-        const int widx = (3 - py - 2 * a) * 4 + (3 - px - 2 * b);
-        const char* gp = p.w + woff + (unsigned)((widx * p.ctot + chunk * 64) * 2);
-        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(smem + T4_WBASE + (step & (T4_WSLOTS - 1)) * T4_WBYTES + wave * 1024), 16, 0, 0);
+    auto stage_patch_piece = [&](const CK& ck, int buf, int j) {
+        buf_dma16(ck.pbase, smem + buf * T4_PATCH + (j * 512 + wave * 64) * 16, pvoff[j], ck.poff);
     };
+    CK ck_cur = make_ck(0), ck_nxt = ck_cur;
+#pragma unroll
+    for (int j = 0; j < T4_PPASS; ++j) stage_patch_piece(ck_cur, 0, j);
 
     f32x16 acc[4][FM];
 #pragma unroll
@@ -130,19 +146,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
         for (int b = 0; b < FM; ++b) fa[b][s2] = bf16x8{};
     }
-    // the reads of k-step S2 of the step with (class, tap) = V, weight slot V & 3, activation base registers ab[]
+    // fragment E (0: weights, 1 + b: activation tile b) of k-step S2 of the step with (class, tap) = V, weight slot V & 3,
+    // activation base registers ab[]
+    auto read_frag = [&](auto v_, auto s2_, auto e_, const unsigned (&ab)[FM]) {
+        constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value, E = decltype(e_)::value;
+        if constexpr (E == 0) t4_rd<(V & 3) * T4_WBYTES>(wadr[S2], fw[S2]);
+        else t4_rd<t4_tap_off(V) + S2 * 32>(ab[E - 1], fa[E - 1][S2]);
+    };
     auto read_kstep = [&](auto v_, auto s2_, const unsigned (&ab)[FM]) {
-        constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value;
-        t4_rd<(V & 3) * T4_WBYTES>(wadr[S2], fw[S2]);
-#pragma unroll
-        for (int b = 0; b < FM; ++b) t4_rd<t4_tap_off(V) + S2 * 32>(ab[b], fa[b][S2]);
+        read_frag(v_, s2_, std::integral_constant<int, 0>{}, ab);
+        read_frag(v_, s2_, std::integral_constant<int, 1>{}, ab);
+        read_frag(v_, s2_, std::integral_constant<int, 2>{}, ab);
     };
 
-    const int nsteps = q.nchunks * 16;
-    // ---- prologue: patch 0, weight stages 0..2
-#pragma unroll
-    for (int j = 0; j < T4_PPASS; ++j) stage_patch_piece(0, j);
-    stage_w(0); stage_w(1); stage_w(2);                      // nsteps >= 16
+    // ---- prologue: patch 0 and the weight stages 0..2 are on their way
     t4_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     unsigned acur[FM] = {abuf[0][0], abuf[0][1]}, aoth[FM] = {abuf[1][0], abuf[1][1]};
@@ -151,14 +168,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, acur);
     read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, acur);
 
-    // one tap step: (class, tap) = V; `more`: a step follows (its fragments are read ahead here)
-    auto body = [&](int i, auto v_, const bool more) {
+    // one tap step of chunk `chunk`: (class, tap) = V; `more`: a step follows (its fragments are read ahead here)
+    auto body = [&](int chunk, auto v_, const bool more) {
         constexpr int V = decltype(v_)::value, NV = (V + 1) & 15, CLS = V >> 2;
+        if constexpr (V == 0) { ck_cur = ck_nxt; ck_nxt = make_ck(chunk + 1); }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const int chunk = i >> 4;
-        const bool w_issued = i + 3 < nsteps;
-        const bool p_issued = V < T4_PPASS && chunk + 1 < q.nchunks;
+        constexpr bool p_issued = V < T4_PPASS;
         auto kstep = [&](auto s2_) {
             constexpr int S2 = decltype(s2_)::value;
             if (more) PFA_WAIT_LGKM((KS - 1) * NR); else PFA_WAIT_LGKM((KS - 1 - S2) * NR);
@@ -166,34 +182,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int b = 0; b < FM; ++b) pin(fa[b][S2]);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < FM; ++b)
-                acc[CLS][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[S2], fa[b][S2], acc[CLS][b], 0, 0, 0);
+            // the k-step's reads and DMA in the shadows of its two MFMAs (see conv_patch2.hip): M(w,a0) [DMA] R(a0) M(w,a1) R(w) R(a1)
+            auto rd = [&](auto e_) {                         // the same k-step of the next tap step, into the registers just consumed
+                if (more) {
+                    if (V == 15) read_frag(std::integral_constant<int, NV>{}, s2_, e_, aoth);     // the next chunk's patch buffer
+                    else read_frag(std::integral_constant<int, NV>{}, s2_, e_, acur);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            acc[CLS][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[S2], fa[0][S2], acc[CLS][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {                                      // the same k-step of the next tap step, into the registers just consumed
-                if (V == 15) read_kstep(std::integral_constant<int, NV>{}, s2_, aoth);     // the next chunk's patch buffer
-                else read_kstep(std::integral_constant<int, NV>{}, s2_, acur);
-            }
-            if (S2 == 0 && w_issued) stage_w(i + 3);
-            if (S2 == 2 && p_issued) stage_patch_piece(chunk + 1, V < T4_PPASS ? V : 0);
+            if (S2 == 0) stage_w(V + 3 < 16 ? ck_cur.woff : ck_nxt.woff, std::integral_constant<int, (V + 3) & 15>{});      // stage i+3
+            if (S2 == 2 && p_issued) stage_patch_piece(ck_nxt, (chunk + 1) & 1, V < T4_PPASS ? V : 0);
             __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, 1>{});
+            acc[CLS][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[S2], fa[1][S2], acc[CLS][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(std::integral_constant<int, 0>{});
+            rd(std::integral_constant<int, 2>{});
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
-        if (w_issued && p_issued) t4_wait_vm<2>();
-        else if (w_issued || p_issued) t4_wait_vm<1>();
-        else t4_wait_vm<0>();
+        t4_wait_vm<p_issued ? 2 : 1>();
     };
-    for (int i = 0; i < nsteps; i += 16) {                   // one 64-channel chunk per trip; every body exists once
-        const bool next = i + 16 < nsteps;
+    for (int chunk = 0; chunk < q.nchunks; ++chunk) {         // one 64-channel chunk per trip; every body exists once
+        const bool next = chunk + 1 < q.nchunks;
         [&]<int... V>(std::integer_sequence<int, V...>) {
-            (body(i + V, std::integral_constant<int, V>{}, V < 15 || next), ...);
+            (body(chunk, std::integral_constant<int, V>{}, V < 15 || next), ...);
         }(std::make_integer_sequence<int, 16>{});
 #pragma unroll
         for (int b = 0; b < FM; ++b) { const unsigned t = acur[b]; acur[b] = aoth[b]; aoth[b] = t; }
     }
+    t4_wait_vm<0>();                             // (the pieces issued behind the last chunk)
 
     // ---- epilogue: four passes (one per parity class) through the fp32 [position][channel] image in LDS
     constexpr int RS = patch_image_stride<T4_BN>();

@@ -149,6 +149,22 @@ __device__ __forceinline__ float l1_tanh_grad(float f, float r, float dgan, floa
     return d * t;
 }
 
+// LDS-DMA in its BUFFER form (buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds): lane's 16 bytes from
+// base + voff (per-lane VGPR) + soff (wave-uniform SGPR) land at lds + lane * 16 (lds wave-uniform, through M0).  What it buys
+// over global_load_lds with a per-lane 64-bit pointer: the part of a piece's address that changes from step to step (channel
+// chunk, tap, parity plane) is ONE scalar, the per-lane part is computed once per workgroup, and a lane that must read zeros
+// (out-of-image pixel, padding piece) carries the offset PFA_DMA_OOB - the range check against num_records = 2 GiB (VGPR +
+// SGPR offset, measured on gfx950: tools/micro/bufdma_check.hip) makes the hardware write zeros to its LDS bytes: no zero
+// page, no select, no 64-bit address arithmetic.  In the patch kernels' K loops that arithmetic was ~2/3 of the instruction
+// stream (profiles/r04_issue_mix.txt).  Every in-range voff + soff must stay below 2 GiB.
+// (A plain function on purpose: written inside a kernel template's lambda the builtin made hipcc drop the kernel's host stub
+// without a diagnostic.)
+constexpr unsigned PFA_DMA_OOB = 0x80000000u;
+__device__ __forceinline__ void buf_dma16(const void* base, void* lds, unsigned voff, unsigned soff) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000u, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(lds), 16, (int)voff, (int)soff, 0, 0);
+}
+
 // XCD-aware work-item id (cdna guide T1, bijective form).  Workgroups are dealt round-robin over the 8 XCDs,
 // each with a private L2: give every XCD one CONTIGUOUS chunk of the work list so that workgroups which share an
 // operand tile hit the same L2.  Placement only changes speed, never results.

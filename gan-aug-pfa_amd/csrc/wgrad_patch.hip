@@ -97,7 +97,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int it = wid % p.itiles;
     const int split = wid / p.itiles;
     const int i0 = it * 128, c0 = ct * 64;
-    const char* zero = (const char*)g_pfa_zero_page;
     auto stamp = [&](int k) {          // shader clock at points of the workgroup's life (a separate measurement, never a result)
         if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memtime();
     };
@@ -108,7 +107,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int nsteps = (nlive + NSTAGE - 1) / NSTAGE * NSTAGE;     // the loop runs whole turns of the ring: the extra steps of the
                                                                    // last slice stage zeros and add nothing
 
-    // ---- DMA roles.  Direct tile: 2 pieces; lane -> (pixel, chunk position).  Edge flags: 1 = beyond the right edge in the
+    // ---- DMA roles (LDS-DMA in the buffer form of pfa_common.h: a per-lane offset that is fixed for the whole loop, ONE
+    // scalar per operand and step for the tile's position, PFA_DMA_OOB where the hardware is to write zeros).
+    // Direct tile: 2 pieces; lane -> (pixel, chunk position).  Edge flags (4 bits per piece): 1 = beyond the right edge in the
     // last tile column, 2 = beyond the bottom edge in the last tile row, 4 = left of the image in the first column,
     // 8 = above the image in the first tile row.
     const bool d_first = i0 < p.d1p;
@@ -122,29 +123,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         const int ch = (cpos ^ ((px & 3) << 2)) * 8;
         const int r = px / TX, cx = px % TX;
         d_off[j] = (unsigned)(((r * p.wq + cx) * dch + di0 + ch) * 2);
-        d_flag |= ((qx_last + cx >= p.wq) ? 1u : 0u) << (4 * j);
-        d_flag |= ((qy_last + r >= p.hq) ? 2u : 0u) << (4 * j);
+        d_flag |= (unsigned)(qx_last + cx >= p.wq) << (4 * j);
+        d_flag |= ((unsigned)(qy_last + r >= p.hq) << 1) << (4 * j);
     }
-    int g_off[PP];               // signed: the patch starts one pixel left of / above the tile
-    unsigned g_flag = 0;
+    // Patch: the tile's pixels start one pixel left of / above the tile: the per-lane offset counts from there and the
+    // gathered operand's base is moved back by one row and one pixel, so that no offset is negative.  A slot no fragment
+    // reads (row padding, the tail of the last pass) carries PFA_DMA_OOB for good.
+    unsigned g_off[PP], g_flag = 0;
 #pragma unroll
     for (int j = 0; j < PP; ++j) {
         const int q = j * 512 + tid, slot = q >> 3, cpos = q & 7;
         const int ch = (cpos ^ (((slot >> 1) & 1) << 2)) * 8;
         const int r = slot / RP, jj = slot - r * RP;
-        int xrel, f = 0;
-        if (STRIDE == 1) { xrel = jj - 1; if (jj >= PLW) f = 16; }
-        else { const int pl = jj / PLW, idx = jj - pl * PLW; xrel = 2 * idx - 1 + pl; if (jj >= 2 * PLW) f = 16; }
+        int xrel; unsigned dead;
+        if (STRIDE == 1) { xrel = jj - 1; dead = (unsigned)(jj >= PLW); }
+        else { const int pl = jj / PLW, idx = jj - pl * PLW; xrel = 2 * idx - 1 + pl; dead = (unsigned)(jj >= 2 * PLW); }
         const int yrel = STRIDE * r - 1 + ky;
-        if (slot >= PSLOTS) f = 16;
-        if (STRIDE * qx_last + xrel >= p.wg) f |= 1;
-        if (STRIDE * qy_last + yrel >= p.hg) f |= 2;
-        if (xrel < 0) f |= 4;
-        if (yrel < 0) f |= 8;
-        g_off[j] = ((yrel * p.wg + xrel) * p.gp + c0 + ch) * 2;
-        g_flag |= (unsigned)f << (5 * j);
+        dead |= (unsigned)(slot >= PSLOTS);
+        const unsigned f = (unsigned)(STRIDE * qx_last + xrel >= p.wg) | ((unsigned)(STRIDE * qy_last + yrel >= p.hg) << 1) |
+                           ((unsigned)(xrel < 0) << 2) | ((unsigned)(yrel < 0) << 3);
+        const unsigned keep = dead - 1u;         // all ones for a live slot
+        g_off[j] = ((unsigned)((((yrel + 1) * p.wg + xrel + 1) * p.gp + c0 + ch) * 2) & keep) | (PFA_DMA_OOB & ~keep);
+        g_flag |= f << (4 * j);
     }
-    // position of the DMA stream (3 steps ahead of the MFMAs): tile (img, ty, tx) of step `ds`
+    const char* const gbase = p.gat - (size_t)(p.wg + 1) * p.gp * 2;
+    // position of the DMA stream (NSTAGE-1 steps ahead of the MFMAs): tile (img, ty, tx) of step `ds`
     int ds = 0, d_tx, d_ty, d_img;
     {
         const int t = step0;
@@ -152,30 +155,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         d_img = t / per; const int rem = t - d_img * per;
         d_ty = rem / p.tiles_x; d_tx = rem - d_ty * p.tiles_x;
     }
-    auto stage = [&](int slot, int op0, int op1) {           // DMA ops [op0, op1) of step ds into ring slot `slot`
-        if (no_dma) return;
+    // what a step's pieces share: the two scalar offsets of its tile (out of range behind the slice's last step: those
+    // pieces are still issued - zeros into a free ring slot, no memory traffic - so every step issues and waits alike) and
+    // the tile's edge mask
+    struct TS { unsigned dsoff, gsoff, emask; };
+    auto tile_state = [&]() -> TS {
         const int qy0 = d_ty * TY, qx0 = d_tx * TX;
         const bool live = ds < nlive;
-        const unsigned emask = (d_tx == p.tiles_x - 1 ? 1u : 0u) | (d_ty == p.tiles_y - 1 ? 2u : 0u) | (d_tx == 0 ? 4u : 0u) |
-                               (d_ty == 0 ? 8u : 0u);
+        TS t;
+        t.emask = (d_tx == p.tiles_x - 1 ? 1u : 0u) | (d_ty == p.tiles_y - 1 ? 2u : 0u) | (d_tx == 0 ? 4u : 0u) | (d_ty == 0 ? 8u : 0u);
+        t.dsoff = live ? (unsigned)(((d_img * p.hq + qy0) * p.wq + qx0) * dch * 2) : PFA_DMA_OOB;
+        t.gsoff = live ? (unsigned)(((d_img * p.hg + STRIDE * qy0) * p.wg + STRIDE * qx0) * p.gp * 2) : PFA_DMA_OOB;
+        return t;
+    };
+    auto stage = [&](const TS& t, int slot, int op0, int op1) {           // DMA ops [op0, op1) of the tile t into ring slot `slot`
+        if (no_dma) return;
         char* sbase = smem + slot * STAGE;
 #pragma unroll
         for (int k = op0; k < op1; ++k) {
             if (k < 2) {
-                const bool ok = live && ((d_flag >> (4 * k)) & emask & 3u) == 0;
-                const char* tb = dbase + (size_t)((d_img * p.hq + qy0) * p.wq + qx0) * dch * 2;
-                const char* gp = ok ? tb + d_off[k] : zero;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(sbase + (k * 512 + wave * 64) * 16), 16, 0, 0);
+                const unsigned v = (d_flag & ((t.emask & 3u) << (4 * k))) ? PFA_DMA_OOB : d_off[k];
+                buf_dma16(dbase, sbase + (k * 512 + wave * 64) * 16, v, t.dsoff);
             } else {
                 const int j = k - 2;
                 if (j == PP - 1 && !last_pass) continue;
-                const unsigned f = (g_flag >> (5 * j)) & 31u;
-                const bool ok = live && (f & (emask | 16u)) == 0;
-                const char* tb = p.gat + ((long long)(d_img * p.hg + STRIDE * qy0) * p.wg + STRIDE * qx0) * p.gp * 2;
-                const char* gp = ok ? tb + g_off[j] : zero;
-                // (every lane takes part: masking the lanes of slots no fragment reads - row padding, the tail of the last
-                // pass - out of the instruction made the step 5 % slower, the DMA is not priced per active lane)
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gp), LDS_PTR(sbase + DIR_BYTES + (j * 512 + wave * 64) * 16), 16, 0, 0);
+                // (every lane takes part: masking the lanes of slots no fragment reads out of the instruction made the step
+                // 5 % slower, the DMA is not priced per active lane)
+                const unsigned v = (g_flag & (t.emask << (4 * j))) ? PFA_DMA_OOB : g_off[j];
+                buf_dma16(gbase, sbase + DIR_BYTES + (j * 512 + wave * 64) * 16, v, t.gsoff);
             }
         }
     };
@@ -230,33 +237,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                 for (int y = 0; y < NKY; ++y) fb[s][y][t][e] = bf16x4{};
             }
     constexpr int NR = 4 + 4 * NKY;           // fragment reads of a k-step
-    auto read_kstep = [&](auto slot_, auto s_) {             // the 8 reads of k-step S of the stage in ring slot SL
+    // fragment group G of k-step S of the stage in ring slot SL: 0 / 1 = direct tile a (two halves), 2 + y * 2 + b = gathered
+    // tile b of tap row y (two halves)
+    auto read_frag = [&](auto slot_, auto s_, auto g_) {
         if (no_read) return;
-        constexpr int SL = decltype(slot_)::value, S = decltype(s_)::value, SET = S & 1;
+        constexpr int SL = decltype(slot_)::value, S = decltype(s_)::value, SET = S & 1, G = decltype(g_)::value;
         constexpr int ppix = TX == 32 ? (S >> 1) * RP + 16 * (S & 1) : S * RP;      // first pixel slot of the k-step's rows
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            tr_rd<(16 * S) * 256>(aadr[a][SL], fa[SET][a][0]);
-            tr_rd<(16 * S + 4) * 256>(aadr[a][SL], fa[SET][a][1]);
+        if constexpr (G < 2) {
+            tr_rd<(16 * S) * 256>(aadr[G][SL], fa[SET][G][0]);
+            tr_rd<(16 * S + 4) * 256>(aadr[G][SL], fa[SET][G][1]);
+        } else {
+            constexpr int Y = (G - 2) >> 1, B = (G - 2) & 1;        // (the second tap row: the same pixels one patch row further down)
+            tr_rd<(ppix + Y * RP) * 128>(badr[B][SL], fb[SET][Y][B][0]);
+            tr_rd<(ppix + Y * RP + 4) * 128>(badr[B][SL], fb[SET][Y][B][1]);
         }
-#pragma unroll
-        for (int y = 0; y < NKY; ++y)          // (the second tap row: the same pixels one patch row further down)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                if (y == 0) {
-                    tr_rd<ppix * 128>(badr[b][SL], fb[SET][0][b][0]);
-                    tr_rd<(ppix + 4) * 128>(badr[b][SL], fb[SET][0][b][1]);
-                } else {
-                    tr_rd<(ppix + RP) * 128>(badr[b][SL], fb[SET][NKY - 1][b][0]);
-                    tr_rd<(ppix + RP + 4) * 128>(badr[b][SL], fb[SET][NKY - 1][b][1]);
-                }
-            }
+    };
+    auto read_kstep = [&](auto slot_, auto s_) {             // all NR reads of k-step S of the stage in ring slot SL
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            (read_frag(slot_, s_, std::integral_constant<int, G>{}), ...);
+        }(std::make_integer_sequence<int, 2 + 2 * NKY>{});
     };
 
     // ---- prologue: stages 0..NSTAGE-2, the fragments of k-steps 0 and 1 of stage 0
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nsteps) { stage(s, 0, NOPS); advance(); }
+    for (int s = 0; s < NSTAGE - 1; ++s) { stage(tile_state(), s, 0, NOPS); advance(); }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     read_kstep(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -266,11 +270,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     // one step on ring slot SL; more: a step follows
     auto body = [&](int i, auto slot_, const bool more) {
         constexpr int SL = decltype(slot_)::value, NSL = (SL + 1) % NSTAGE, DSL = (SL + NSTAGE - 1) % NSTAGE;
+        const TS ts = tile_state();              // the tile staged during this step: NSTAGE-1 ahead, into the slot stage i-1 has left
         if constexpr (NSTAGE == 4) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
-        const bool issue = i + NSTAGE - 1 < nsteps;          // the stage NSTAGE-1 ahead into the slot stage i-1 has left
         auto kstep = [&](auto s_) {
             constexpr int S = decltype(s_)::value, SET = S & 1;
             // fragments of this k-step have landed: the reads issued after them are those of the next k-step (8), if any
@@ -284,27 +288,36 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
                     for (int y = 0; y < NKY; ++y) pin(fb[SET][y][t][e]);
                 }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const bf16x8 av = __builtin_shufflevector(fa[SET][a][0], fa[SET][a][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                for (int y = 0; y < NKY; ++y)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const bf16x8 bv = __builtin_shufflevector(fb[SET][y][b][0], fb[SET][y][b][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        if (!no_mfma) acc[y][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[y][a][b], 0, 0, 0);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            auto mfma = [&](auto a_, auto y_, auto b_) {
+                constexpr int A = decltype(a_)::value, Y = decltype(y_)::value, B = decltype(b_)::value;
+                const bf16x8 av = __builtin_shufflevector(fa[SET][A][0], fa[SET][A][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 bv = __builtin_shufflevector(fb[SET][Y][B][0], fb[SET][Y][B][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (!no_mfma) acc[Y][A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[Y][A][B], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             // two k-steps ahead, into the registers just consumed
-            if constexpr (S < 2) read_kstep(slot_, std::integral_constant<int, S + 2>{});
-            else if (more) read_kstep(std::integral_constant<int, NSL>{}, std::integral_constant<int, S - 2>{});
+            auto rd = [&](auto g_) {
+                if constexpr (S < 2) read_frag(slot_, std::integral_constant<int, S + 2>{}, g_);
+                else if (more) read_frag(std::integral_constant<int, NSL>{}, std::integral_constant<int, S - 2>{}, g_);
+                __builtin_amdgcn_sched_barrier(0);
+            };
             // this step's DMA, spread over the k-steps (three stages: over the two behind the barrier)
-            if (issue) {
-                if constexpr (NSTAGE == 4) stage(DSL, (S * NOPS) / 4, ((S + 1) * NOPS) / 4);
-                else if constexpr (S >= 2) stage(DSL, ((S - 2) * NOPS) / 2, ((S - 1) * NOPS) / 2);
+            auto dma = [&]() {
+                if constexpr (NSTAGE == 4) stage(ts, DSL, (S * NOPS) / 4, ((S + 1) * NOPS) / 4);
+                else if constexpr (S >= 2) stage(ts, DSL, ((S - 2) * NOPS) / 2, ((S - 1) * NOPS) / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            if constexpr (NKY == 1) {
+                // the k-step's other instructions in the shadows of its own MFMAs (see conv_patch2.hip): a fragment group is
+                // read again as soon as the last MFMA that takes its old value has been issued
+                mfma(I0{}, I0{}, I0{}); dma(); mfma(I1{}, I0{}, I0{}); rd(I2{}); mfma(I0{}, I0{}, I1{}); rd(I0{}); mfma(I1{}, I0{}, I1{}); rd(I1{}); rd(I3{});
+            } else {
+                mfma(I0{}, I0{}, I0{}); dma(); mfma(I1{}, I0{}, I0{}); rd(I2{}); mfma(I0{}, I0{}, I1{}); mfma(I1{}, I0{}, I1{}); rd(I3{});
+                mfma(I0{}, I1{}, I0{}); mfma(I1{}, I1{}, I0{}); rd(std::integral_constant<int, 4>{});
+                mfma(I0{}, I1{}, I1{}); rd(I0{}); mfma(I1{}, I1{}, I1{}); rd(I1{}); rd(std::integral_constant<int, 5>{});
             }
-            __builtin_amdgcn_sched_barrier(0);
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
@@ -315,14 +328,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         }
         kstep(std::integral_constant<int, 2>{});
         kstep(std::integral_constant<int, 3>{});
+        advance();
         if constexpr (NSTAGE == 4) {
-            if (issue) {
-                advance();
-                if (no_dma) wait_vm<0>();
-                else if (last_pass) wait_vm<NOPS>();
-                else wait_vm<NOPS - 1>();
-            } else wait_vm<0>();
-        } else if (issue) advance();
+            if (no_dma) wait_vm<0>();
+            else if (last_pass) wait_vm<NOPS>();
+            else wait_vm<NOPS - 1>();
+        }
     };
     for (int i = 0; i < nsteps; i += NSTAGE) {
         body(i, std::integral_constant<int, 0>{}, true);
@@ -334,6 +345,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             body(i + 2, std::integral_constant<int, 2>{}, i + 3 < nsteps);
         }
     }
+    wait_vm<0>();                                // (the pieces issued behind the slice's end)
 
     stamp(2);
     // ---- epilogue: lane holds D[i = 8 g + 4 lh' + r][c = lane & 31] of tile (a, b): rows = direct channels, columns = gathered
@@ -434,7 +446,7 @@ bool pfa_wgrad_patch_plan(const pfa_wgrad_args* a, int* slices, int* tx_out, int
     if (a->d1r != a->d1p || a->d2r != a->d2p || a->g1r != a->g1p) return false;
     if (a->wq < 16 || (long long)a->hq * a->wq < 64) return false;
     const long long dbytes = (long long)a->nb * a->hq * a->wq * (a->d1p > a->d2p ? a->d1p : a->d2p) * 2;
-    const long long gbytes = (long long)a->nb * a->hg * a->wg * a->g1p * 2;
+    const long long gbytes = ((long long)a->nb * a->hg * a->wg + a->wg + 2) * a->g1p * 2;     // (+ the one row and pixel the per-lane offsets are shifted by)
     if (dbytes >= (1ll << 31) || gbytes >= (1ll << 31)) return false;
     const int tx = a->wq >= 24 ? 32 : 16, ty = 64 / tx;
     const int steps = a->nb * ((a->hq + ty - 1) / ty) * ((a->wq + tx - 1) / tx);

@@ -166,10 +166,11 @@ def lib():
     """The loaded library.  Raises if libpfa_hip.so has not been built (run __graft_entry__.build())."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise PfaError(f"{LIB_PATH} is missing: the HIP extension is mandatory, build it with "
+        path = os.environ.get("PFA_LIB") or LIB_PATH      # PFA_LIB: another BUILD of this library (same-box A/B of two builds)
+        if not os.path.exists(path):
+            raise PfaError(f"{path} is missing: the HIP extension is mandatory, build it with "
                            f"`make -C {PKG_DIR}` (or __graft_entry__.build()); there is no fallback path")
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)   # AttributeError if the .so does not export a declared symbol
             fn.restype = res

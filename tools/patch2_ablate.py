@@ -12,11 +12,11 @@ shapes = [("e2/c2 fwd K=1024", [T(B, 128, 128, 64)], T(128, 16, 64), 128, (B, 64
           ("d2-dgrad-like K=1024 n=256", [T(B, 128, 128, 64)], T(256, 16, 64), 256, (B, 64, 64)),
           ("K=4096 (256 ch)", [T(B, 128, 128, 256)], T(128, 16, 256), 128, (B, 64, 64))]
 names = {0: "full", 11: "no MFMA", 12: "no reads", 14: "no DMA", 13: "no MFMA, no reads", 15: "no MFMA, no DMA", 16: "no reads, no DMA",
-         17: "barriers + waits + addresses only"}
+         17: "barriers + waits + addresses only", 18: "full, no counted vmcnt wait in the loop", 19: "full, no vmcnt wait, no barrier"}
 for sname, srcs, w, n, grid in shapes:
     o = torch.empty((B, 64, 64, n), device='cuda', dtype=dt)
     print(sname)
-    for knob in (0, 11, 12, 14, 13, 15, 16, 17):
+    for knob in (0, 18, 19, 11, 12, 14, 13, 15, 16, 17):
         lib.pfa_set_knob(7, knob)
         for _ in range(2):
             K.gather_gemm(K.CONV_S2, srcs, w, n, [o], grid, ws)
