@@ -33,12 +33,25 @@ std::mutex g_rccl_mutex;
 int load_rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return 0;
+    // An RCCL the process has already mapped (torch brings its own copy) is reused: a second copy beside it would mean two
+    // sets of communicator state and symbol interposition between them.  Only if none is mapped is one loaded, privately.
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    char tried[384] = "";
+    static const char* const names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char* name : names) {
+        h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         if (h) break;
     }
-    if (!h) PFA_FAIL(-1, "pfa_comm: RCCL not found (%s)", dlerror());
+    for (const char* name : names) {
+        if (h) break;
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char* e = dlerror();
+            const size_t used = strlen(tried);
+            snprintf(tried + used, sizeof(tried) - used, "%s%s: %s", used ? "; " : "", name, e ? e : "?");
+        }
+    }
+    if (!h) PFA_FAIL(-1, "pfa_comm: RCCL not found (%s)", tried);
     Rccl r;
     r.get_unique_id = (decltype(r.get_unique_id))dlsym(h, "ncclGetUniqueId");
     r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(h, "ncclCommInitRank");
@@ -85,8 +98,13 @@ extern "C" int pfa_comm_create(const void* unique_id, int bytes, int nranks, int
 
 extern "C" int pfa_comm_destroy(pfa_comm* c) {
     if (!c) return 0;
-    PFA_REQUIRE(g_rccl.handle, "pfa_comm_destroy: no communicator was ever created");
-    const ncclResult_t r = g_rccl.comm_destroy(c->comm);
+    decltype(g_rccl.comm_destroy) destroy;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        PFA_REQUIRE(g_rccl.handle, "pfa_comm_destroy: no communicator was ever created");
+        destroy = g_rccl.comm_destroy;
+    }
+    const ncclResult_t r = destroy(c->comm);
     delete c;
     if (r != ncclSuccess) PFA_FAIL((int)r, "ncclCommDestroy: %s", g_rccl.error_string(r));
     return 0;

@@ -66,14 +66,17 @@ template <int OFF> __device__ __forceinline__ void lds_rd(unsigned addr, bf16x8&
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(v) : "v"(addr), "n"(OFF));
 }
 
-// MODE 0 = PFA_TCONV_S2, 1 = PFA_CONV_S2.  TILE16: 16 x 16 position tile instead of 8 x 32.  BN: 128 or 64 output channels.
+// MODE 0 = PFA_TCONV_S2, 1 = PFA_CONV_S2.  TILE16: 0 = 8 x 32 position tile, 1 = 16 x 16, 2 = FOUR IMAGES x 8 x 8 (the 8 x 8 maps of the
+// generator's fifth level: e5 / d5 and their input gradients - four 9 x 9 patches in the patch buffer, a wave per image).
+// BN: 128 or 64 output channels.
 // ABL: ablation bits of a diagnostic instantiation (1 no MFMA, 2 no fragment reads, 4 no DMA - results are wrong); 0 in every
 // instantiation the library launches.
 template <int MODE, int BN, int TILE16, int ABL = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_patch2(const Patch2K q) {
     typedef bf16_t T;
-    constexpr int TY = TILE16 ? 16 : 8, TX = TILE16 ? 16 : 32;
-    constexpr int PH = TY + 1, PW = TX + 1, PSLOTS = PH * PW;
+    constexpr int NIMG = TILE16 == 2 ? 4 : 1;              // images of a tile
+    constexpr int TY = TILE16 == 1 ? 16 : 8, TX = TILE16 == 1 ? 16 : TILE16 == 2 ? 8 : 32;
+    constexpr int PH = TY + 1, PW = TX + 1, PSLOTS = NIMG * PH * PW;
     constexpr int FN = BN / 64, FM = 2;                    // 4 x 2 waves: 64 positions x BN/2 channels per wave, 32x32 tiles
     constexpr int KS = 4;                                  // MFMA k-steps (16 channels) per 64-channel chunk
     constexpr int W_BYTES = BN * 128, WP = BN / 64;        // weight tile of a step, DMA pieces per wave
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     int cls = 0;
     if (MODE == 0) { cls = wid & 3; wid >>= 2; }
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
-    const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
+    const int ty = wid % q.tiles_y, img = (int)(wid / q.tiles_y) * NIMG;      // (the tile's first image)
     const int py = cls >> 1, px = cls & 1;
     const int qy0 = ty * TY, qx0 = tx * TX, n0 = nt * BN;
     auto stamp = [&](int k) {          // shader clock at four points of the workgroup's life (a separate measurement, never a result)
@@ -159,14 +162,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for (int j = 0; j < PPASS; ++j) {
         const int qq = j * 512 + tid, slot = qq / 9, g = qq - slot * 9;
-        const int sy = slot / PW, sx = slot - sy * PW;
-        const bool inb = g < 8 && slot < PSLOTS;
+        const int il = NIMG == 1 ? 0 : slot / (PH * PW), rs = slot - il * (PH * PW);      // image of the tile, slot inside its patch
+        const int sy = rs / PW, sx = rs - sy * PW;
+        const bool inb = g < 8 && slot < PSLOTS && img + il < p.nb;
         unsigned pix, any;               // (validity as 0 / 1 integers and bitwise operators: `&&` / `||` / `?:` on per-lane
                                          //  conditions compile to exec-masked branches, two dozen of them in this prologue)
         if (MODE == 0) {
             const int iy = qy0 + py - 1 + sy, ix = qx0 + px - 1 + sx;
             any = (unsigned)inb & (unsigned)((unsigned)iy < (unsigned)p.hs) & (unsigned)((unsigned)ix < (unsigned)p.ws);
-            pix = (unsigned)((img * p.hs + iy) * p.ws + ix);
+            pix = (unsigned)(((img + il) * p.hs + iy) * p.ws + ix);
         } else {
             const int iy = 2 * (qy0 + sy) - 1, ix = 2 * (qx0 + sx) - 1;
             const unsigned y0 = (unsigned)((unsigned)iy < (unsigned)p.hs), y1 = (unsigned)((unsigned)(iy + 1) < (unsigned)p.hs);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             const unsigned b4 = (0u - in1) & ((y0 & x0) | ((y0 & x1) << 8) | ((y1 & x0) << 16) | ((y1 & x1) << 24));     // plane (ey, ex) -> bit 8 (2 ey + ex)
             pok |= b4 << j;
             any = b4 != 0u;
-            pix = (unsigned)((img * p.hs + iy + 1) * p.ws + ix + 1);
+            pix = (unsigned)(((img + il) * p.hs + iy + 1) * p.ws + ix + 1);
         }
         const unsigned keep = 0u - any;          // all ones where the lane reads pixels in some step
         pvoff[j] = ((pix * C2 + (unsigned)g * 16) & keep) | (PFA_DMA_OOB & ~keep);
@@ -232,7 +236,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
         int trow_, tcol_;
-        if (TILE16) { trow_ = wm * 4 + 2 * b + (lr >> 4); tcol_ = ((lr & 15) - (lr >> 4) * (PW & 15)) & 15; }
+        if (TILE16 == 2) {       // wave wm = image wm of the tile; tile b = its rows 4 b .. 4 b + 3 (4 x 8 positions)
+            trow_ = 4 * b + (lr >> 3); tcol_ = lr & 7;
+            tpos[b] = wm * 64 + trow_ * 8 + tcol_;
+            abyte[b] = lds0 + ((wm * PH + trow_) * PW + tcol_) * PSTRIDE + lh * 16;
+            continue;
+        }
+        if (TILE16 == 1) { trow_ = wm * 4 + 2 * b + (lr >> 4); tcol_ = ((lr & 15) - (lr >> 4) * (PW & 15)) & 15; }
         else { trow_ = wm * 2 + b; tcol_ = lr; }
         tpos[b] = trow_ * TX + tcol_;
         abyte[b] = lds0 + (trow_ * PW + tcol_) * PSTRIDE + lh * 16;
@@ -383,12 +393,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     __syncthreads();
     stamp(3);
     auto pix_of = [&](int r, bool& valid, size_t& opix) {
-        const int qy = qy0 + r / TX, qx = qx0 + r % TX;
-        valid = qy < p.hq && qx < p.wq;
-        if (MODE == 0) opix = valid ? ((size_t)img * p.ho + 2 * qy + py) * p.wo + 2 * qx + px : 0;
-        else opix = valid ? ((size_t)img * p.hq + qy) * p.wq + qx : 0;
+        const int il = NIMG == 1 ? 0 : r / (TY * TX), rr = r - il * (TY * TX);
+        const int qy = qy0 + rr / TX, qx = qx0 + rr % TX, im = img + il;
+        valid = qy < p.hq && qx < p.wq && im < p.nb;
+        if (MODE == 0) opix = valid ? ((size_t)im * p.ho + 2 * qy + py) * p.wo + 2 * qx + px : 0;
+        else opix = valid ? ((size_t)im * p.hq + qy) * p.wq + qx : 0;
     };
-    const size_t trow = (((size_t)img * q.tiles_y + ty) * q.tiles_x + tx) * (MODE == 0 ? 4 : 1) + cls;
+    const size_t trow = (((size_t)(img / NIMG) * q.tiles_y + ty) * q.tiles_x + tx) * (MODE == 0 ? 4 : 1) + cls;
     patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of, q.stamps ? q.stamps + (size_t)blockIdx.x * 16 : nullptr);
     if (q.stamps) {
         stamp(6);
@@ -421,16 +432,18 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
     if (pfa_knob(3) == 1 || pfa_knob(3) == 3) return false;             // knob 3: 1 = no patch kernels at all, 3 = stride-1 only
     if (dtype != PFA_BF16 || !(k.mode == PFA_TCONV_S2 || k.mode == PFA_CONV_S2) || !k.small32) return false;
     if (k.c1 % 64 || k.c2 % 64 || k.n % 64 || k.act == PFA_ACT_TANH) return false;
-    if (k.hq < 8 || k.wq < 16) return false;
+    const bool tile_img = k.hq == 8 && k.wq == 8 && !(pfa_knob(1) & 4096);   // the 8 x 8 maps: four images per tile (knob 1 bit 4096: off, A/B)
+    if (!tile_img && (k.hq < 8 || k.wq < 16)) return false;
     // buffer-form LDS-DMA: every in-range offset stays below 2 GiB
     if (((long long)k.nb * k.hs * k.ws + k.ws + 2) * (k.c1 > k.c2 ? k.c1 : k.c2) * 2 >= (1LL << 31) || (long long)k.n * 16 * k.ctot * 2 >= (1LL << 31))
         return false;
     Patch2Plan pl{};
-    pl.tile16 = k.wq < 32 ? 1 : 0;
-    const int tyy = pl.tile16 ? 16 : 8, txx = pl.tile16 ? 16 : 32;
+    pl.tile16 = tile_img ? 2 : k.wq < 32 ? 1 : 0;
+    const int tyy = pl.tile16 == 1 ? 16 : 8, txx = pl.tile16 == 1 ? 16 : pl.tile16 == 2 ? 8 : 32;
     pl.tiles_y = (k.hq + tyy - 1) / tyy; pl.tiles_x = (k.wq + txx - 1) / txx;
     const int classes = k.mode == PFA_TCONV_S2 ? 4 : 1;
-    const long long tiles = (long long)k.nb * pl.tiles_y * pl.tiles_x * classes;
+    const int groups = pl.tile16 == 2 ? (k.nb + 3) / 4 : k.nb;           // image groups of the work list
+    const long long tiles = (long long)groups * pl.tiles_y * pl.tiles_x * classes;
     const int nss = (k.ctot / 64) * (k.mode == PFA_CONV_S2 ? 4 : 1);
     // (in-situ sweep of the threshold: 192 -> 3.41 ms per step, 128 -> 3.37, 256 -> 3.47, 320 -> 3.65: a launch that leaves CUs
     // idle is not lost inside the three-stream step, narrower tiles are)
@@ -439,6 +452,14 @@ bool pfa_conv_patch2_plan(const GatherK& k, int dtype, Patch2Plan* plan) {
     const int want = pfa_knob(6) > 0 ? pfa_knob(6) : (pfa_knob(15) ? 192 : 128);
     pl.splitk = 1;
     if (k.n % 128 == 0 && tiles * (k.n / 128) >= want) pl.bn = 128;
+    else if (tile_img && k.n % 128 == 0 && k.splitk > 1) {
+        // the 8 x 8 maps have 4 .. 16 position tiles at batch 16: 128-channel tiles (weight bytes per FLOP) and K slices
+        pl.bn = 128;
+        int sk = k.splitk < nss ? k.splitk : nss;
+        while (sk > 2 && tiles * (k.n / 128) * (sk / 2) >= want) sk /= 2;
+        while (nss % sk) --sk;                                             // (whole super-steps per slice, none empty)
+        pl.splitk = sk;
+    }
     else if (tiles * (k.n / 64) >= want || k.splitk <= 1) pl.bn = 64;
     else {
         pl.bn = 64;
@@ -462,13 +483,25 @@ int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, co
     q.tiles_y = plan.tiles_y; q.tiles_x = plan.tiles_x;
     q.ntiles = k.n / plan.bn;
     const int classes = k.mode == PFA_TCONV_S2 ? 4 : 1;
-    q.nwg = k.nb * plan.tiles_y * plan.tiles_x * classes * q.ntiles * plan.splitk;
+    q.nwg = (plan.tile16 == 2 ? (k.nb + 3) / 4 : k.nb) * plan.tiles_y * plan.tiles_x * classes * q.ntiles * plan.splitk;
     q.nss = (k.ctot / 64) * (k.mode == PFA_CONV_S2 ? 4 : 1);
     q.ssper = (q.nss + plan.splitk - 1) / plan.splitk;
     PFA_REQUIRE((q.nss + q.ssper - 1) / q.ssper == plan.splitk, "pfa_conv_patch2: empty K slice");
     q.c1chunks = k.c1 / 64;
     q.stamps = nullptr;
     if (g_pfa_dbgbuf && g_pfa_dbgbuf_bytes >= (size_t)q.nwg * 128) q.stamps = (unsigned long long*)g_pfa_dbgbuf;
+    if (plan.tile16 == 2) {
+        static const char* names2[4] = {"k_conv_patch2<tconv,128,4x8x8>", "k_conv_patch2<tconv,64,4x8x8>", "k_conv_patch2<conv_s2,128,4x8x8>",
+                                        "k_conv_patch2<conv_s2,64,4x8x8>"};
+        const int sel2 = (k.mode == PFA_CONV_S2 ? 2 : 0) + (plan.bn == 64 ? 1 : 0);
+        if (kernel_name) *kernel_name = names2[sel2];
+        switch (sel2) {
+            case 0: return launch_patch2<0, 128, 2>(q, st);
+            case 1: return launch_patch2<0, 64, 2>(q, st);
+            case 2: return launch_patch2<1, 128, 2>(q, st);
+            default: return launch_patch2<1, 64, 2>(q, st);
+        }
+    }
     const int sel = (k.mode == PFA_CONV_S2 ? 4 : 0) + (plan.bn == 64 ? 2 : 0) + (plan.tile16 ? 1 : 0);
     static const char* names[8] = {"k_conv_patch2<tconv,128,8x32>", "k_conv_patch2<tconv,128,16x16>", "k_conv_patch2<tconv,64,8x32>",
                                    "k_conv_patch2<tconv,64,16x16>", "k_conv_patch2<conv_s2,128,8x32>", "k_conv_patch2<conv_s2,128,16x16>",

@@ -219,8 +219,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 
     // ---- epilogue: four passes (one per parity class) through the fp32 [position][channel] image in LDS
     constexpr int RS = patch_image_stride<T4_BN>();
-#pragma unroll
-    for (int cls = 0; cls < 4; ++cls) {
+    // (one pass per class through a fold expression, not a `#pragma unroll` loop: were the compiler to leave that loop rolled -
+    // its body is the whole row epilogue - acc[cls] would be indexed at run time and the accumulators would live in scratch)
+    auto class_pass = [&](auto cls_) {
+        constexpr int cls = decltype(cls_)::value;
         __syncthreads();                         // staging buffers / the previous class's image are free
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             }
         }
         __syncthreads();
-        const int py = cls >> 1, px = cls & 1;
+        constexpr int py = cls >> 1, px = cls & 1;
         auto pix_of = [&](int r, bool& valid, size_t& opix) {
             const int qy = qy0 + r / T4_TX, qx = qx0 + r % T4_TX;
             valid = qy < p.hq && qx < p.wq;
@@ -240,7 +242,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         };
         const size_t trow = (((size_t)img * q.tiles_y + ty) * q.tiles_x + tx) * 4 + cls;
         patch_epilogue_rows<T4_BN>(p, n0, tid, 0, trow, smem, pix_of);
-    }
+    };
+    class_pass(std::integral_constant<int, 0>{});
+    class_pass(std::integral_constant<int, 1>{});
+    class_pass(std::integral_constant<int, 2>{});
+    class_pass(std::integral_constant<int, 3>{});
 }
 
 }  // namespace

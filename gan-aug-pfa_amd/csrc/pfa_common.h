@@ -124,8 +124,9 @@ template <> struct Chunk<bf16_t> {
 // whole-row epilogues spent most of their time in them; kernels hoist act_neg() out of their element loops.
 __device__ __forceinline__ float act_neg(int act, float slope) { return act == PFA_ACT_LRELU ? slope : act == PFA_ACT_RELU ? 0.f : 1.f; }
 // (neg == 0 selects a literal 0: -inf * 0 would be NaN where torch.relu gives 0 - a bf16 conv output that overflowed must
-// not poison the BatchNorm statistics behind it; the test on `neg` is uniform and hoists with it)
-__device__ __forceinline__ float act_lin(float v, float neg) { return v > 0.f ? v : (neg != 0.f ? v * neg : 0.f); }
+// not poison the BatchNorm statistics behind it; the test on `neg` is uniform and hoists with it.  A NaN stays a NaN, as in
+// torch.relu: a diverged run must show it, not train on zeros.)
+__device__ __forceinline__ float act_lin(float v, float neg) { return v > 0.f ? v : (neg != 0.f ? v * neg : (v != v ? v : 0.f)); }
 __device__ __forceinline__ float act_grad_lin(float y, float neg) { return y > 0.f ? 1.f : neg; }
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == PFA_ACT_TANH) return tanhf(v);

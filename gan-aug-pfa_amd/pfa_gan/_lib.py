@@ -200,6 +200,7 @@ class LaunchList:
         # addresses (the step's input tensors) when the list was recorded; replay(subst=) rewrites them, so ONE list serves
         # any buffer of the same shape (no copy into static inputs in front of each replay)
         self._sites = {int(p): [] for p in patch}
+        self._current = {}              # patch address -> the address its sites hold now (absent: as recorded)
         if self._sites:
             for obj in keep:
                 if isinstance(obj, Structure):
@@ -212,11 +213,16 @@ class LaunchList:
         return len(self._sites.get(int(ptr), ()))
 
     def replay(self, subst=None):
-        """subst: {recorded address: address to use from now on} for addresses given to Recorder.finish(patch=...)."""
-        if subst:
-            for orig, new in subst.items():
-                for obj, name in self._sites[int(orig)]:
-                    setattr(obj, name, int(new))
+        """subst: {recorded address: address this replay uses} for addresses given to Recorder.finish(patch=...).  Every
+        patch address that subst does not name goes back to the address it was recorded with: a replay never inherits the
+        buffers of an earlier one (a batch that had to be copied into the static inputs behind one that was substituted)."""
+        subst = subst or {}
+        for orig, sites in self._sites.items():
+            new = int(subst.get(orig, orig))
+            if self._current.get(orig, orig) != new:
+                for obj, name in sites:
+                    setattr(obj, name, new)
+                self._current[orig] = new
         failed = c_int(-1)
         rc = _LIB.pfa_replay(ctypes.addressof(self.ops), self.n, ctypes.byref(failed))
         if rc != 0:

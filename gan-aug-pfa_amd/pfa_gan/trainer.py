@@ -205,6 +205,7 @@ class GanTrainer:
             raise PfaError(f"GanTrainer(collectives={collectives!r}): 'torch' or 'c'")
         # (created here, while every rank is in the constructor: the communicator's set-up is itself a collective)
         self.ccomm = K.Comm.from_process_group(process_group) if process_group is not None and collectives == "c" else None
+        self._comm_stream = None             # collectives='c': the one stream every pfa_allreduce of this trainer runs on
         self.skip_collectives = False        # bench.py's comm-off timing pass (never set in training)
         dev = self.G.device
         self.gctx, self.ctx_r, self.ctx_f = self.G.new_ctx(), self.Dn.new_ctx(), self.Dn.new_ctx()
@@ -238,6 +239,12 @@ class GanTrainer:
         self._graph_one_stream = False
         self.G.refresh_shadows(force=True)
         self.Dn.refresh_shadows(force=True)
+
+    def close(self):
+        """Release what the trainer holds outside torch: the C-boundary communicator (collectives='c')."""
+        if self.ccomm is not None:
+            self.ccomm.close()
+            self.ccomm = None
 
     # ----------------------------------------------------------------------------------- pieces of a step
     def _mark(self, name, stream=None):
@@ -538,6 +545,8 @@ class GanTrainer:
             self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
             self.G.refresh_shadows(force=True)
         K.axpy(self.loss_sums, self.losses)
+        if self._solo_default():             # the hint is process-wide library state: a step does not leave it set for whatever
+            K.set_solo(False)                # launches next (eval forwards, another trainer); phases set it again
 
     def _reduce(self, t, key, async_op=False):
         """Sum-all-reduce of a float32 gradient range over the ranks on the current stream; returns a handle with .wait()
@@ -557,16 +566,30 @@ class GanTrainer:
                 buf = self._payload[key] = torch.empty(t.numel(), dtype=torch.bfloat16, device=t.device)
             buf.copy_(t)
         if self.ccomm is not None:
-            # the library's communicator: the collective is ordered on the current stream (behind the range's producers,
-            # which the caller has made this stream wait for; in front of whatever this stream does next)
-            self.ccomm.allreduce(t if buf is None else buf)
-            if buf is not None:
-                t.copy_(buf)
+            # The library's communicator.  Every collective of the trainer goes through ONE communication stream, in program
+            # order (the same on every rank): RCCL does not allow one communicator's operations to run concurrently from several
+            # streams, and the step issues its ranges from three.  The stream waits for the calling stream (the range's
+            # producers, the payload copy above); the caller - or whoever calls wait() - waits for the completion event.
+            cur = torch.cuda.current_stream()
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=t.device)
+            cs = self._comm_stream
+            K.wait_stream(cs, cur)
+            with torch.cuda.stream(cs):
+                self.ccomm.allreduce(t if buf is None else buf)
+                if buf is not None:
+                    t.copy_(buf)
+            done = torch.cuda.Event()
+            K.record_event(done, cs)
 
-            class _InStream:
-                def wait(self_inner):
-                    pass
-            return _InStream() if async_op else None
+            class _OnCommStream:
+                def wait(self_inner):        # the then-current stream waits; never the host
+                    K.wait_event(torch.cuda.current_stream(), done)
+            h = _OnCommStream()
+            if async_op:
+                return h
+            h.wait()
+            return None
         work = torch.distributed.all_reduce(buf, group=self.pg, async_op=True)
 
         class _Back:
@@ -611,6 +634,8 @@ class GanTrainer:
             self._graph_one_stream = bool(self.use_graph)
         if self.use_graph and (self._static is None or self._static[0].shape == xa.shape):
             return self._step_graph(xa, xb)       # (a batch of another shape, e.g. a ragged last one, runs eagerly)
+        if not (xa.is_contiguous() and xb.is_contiguous()):      # the kernels take the dense NHWC tensors pack() returns
+            xa, xb = xa.contiguous(), xb.contiguous()
         self._d_phase(xa, xb, False, ready if self.side is not None else None)
         self._allreduce(self.opt_d)
         self._d_update_g_phase(xa, xb, False)
@@ -673,8 +698,11 @@ class GanTrainer:
             raise PfaError("GanTrainer(use_graph='replay'): the launch lists were recorded on another current stream")
         sa, sb = self._static
         subst = None
-        if self.use_graph == "replay" and xa.is_contiguous() and xb.is_contiguous():
+        def takes(x, s):                          # x can stand in for the recorded buffer s as it is
+            return x.is_contiguous() and x.shape == s.shape and x.dtype == s.dtype and x.device == s.device
+        if self.use_graph == "replay" and takes(xa, sa) and takes(xb, sb):
             # a launch list takes the batch's own buffers: the recorded input addresses are rewritten, nothing is copied
+            # (a later replay without subst puts the recorded addresses back: LaunchList.replay)
             subst = {sa.data_ptr(): xa.data_ptr(), sb.data_ptr(): xb.data_ptr()}
         else:
             sa.copy_(xa)

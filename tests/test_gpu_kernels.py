@@ -267,6 +267,13 @@ PATCH2_CASES = [  # name, kind, N, cin parts, H, W (input), Co, K slices, knob 6
     ("conv_split_out", "conv", 2, [64], 32, 64, 128, 1, 1, "k_conv_patch2<conv_s2,128,8x32>", 64),    # two outputs (decoder dgrad)
     ("conv_sliced", "conv", 1, [128], 32, 32, 64, 4, 0, "k_conv_patch2<conv_s2,64,16x16>", None),      # 8 super-steps in 4 slices
     ("conv_cat", "conv", 1, [64, 128], 36, 32, 64, 1, 0, "k_conv_patch2<conv_s2,64,16x16>", None),     # two sources of unequal width
+    # 8 x 8 position maps: four images per tile (the generator's fifth level, e5 / d5 and their input gradients)
+    ("conv_img4", "conv", 6, [64], 16, 16, 128, 1, 1, "k_conv_patch2<conv_s2,128,4x8x8>", None),       # 6 images: a ragged second tile
+    ("conv_img4_sliced", "conv", 4, [128], 16, 16, 128, 4, 0, "k_conv_patch2<conv_s2,128,4x8x8>", None),   # 8 super-steps in 4 slices
+    ("conv_img4_64", "conv", 5, [64, 64], 16, 16, 64, 1, 1, "k_conv_patch2<conv_s2,64,4x8x8>", None),  # 64-channel tile, two sources
+    ("conv_img4_split", "conv", 4, [64], 16, 16, 256, 2, 0, "k_conv_patch2<conv_s2,128,4x8x8>", 128),  # two outputs (d5's input gradient)
+    ("tconv_img4", "tconv", 5, [64, 64], 8, 8, 128, 1, 1, "k_conv_patch2<tconv,128,4x8x8>", None),     # virtual concat, ragged tile
+    ("tconv_img4_sliced", "tconv", 4, [128, 64], 8, 8, 128, 3, 0, "k_conv_patch2<tconv,128,4x8x8>", None),   # 3 chunks in 3 slices, unequal sources
 ]
 
 

@@ -1292,6 +1292,36 @@ def test_launch_lists_take_the_batches_own_buffers():
     assert torch.isfinite(l8).all()
 
 
+def test_launch_lists_fall_back_to_the_static_inputs_behind_a_substituted_batch():
+    """A batch the lists cannot take as it is (not contiguous) is copied into the static inputs, and the replay must read
+    THEM - not the buffers the previous, substituted replay left in the argument blocks (round-3 advisor finding): contiguous,
+    strided, contiguous batches give what the eager step gives on the same tensors."""
+    def run(mode):
+        torch.manual_seed(5)
+        G = pfa_gan.UNetGenerator(3, 3, num_downs=5, ngf=8).cuda()
+        D = pfa_gan.NLayerDiscriminator(6, ndf=8).cuda()
+        tr = pfa_gan.GanTrainer(G, D, precision="bf16", inputs_resident=True, use_graph=mode)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        packs = []
+        for _ in range(3):
+            a = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+            b = torch.rand((2, 3, 64, 64), device="cuda", generator=g) * 2 - 1
+            packs.append((tr.pack(a), tr.pack(b)))
+        # the middle batch lives in every second row of a larger buffer: same values, not contiguous
+        wide = [torch.empty((x.shape[0] * 2,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for x in packs[1]]
+        for w, x in zip(wide, packs[1]):
+            w[::2].copy_(x)
+        seq = [packs[0], (wide[0][::2], wide[1][::2]), packs[2], packs[0]]
+        assert not seq[1][0].is_contiguous() and torch.equal(seq[1][0], packs[1][0])
+        torch.cuda.synchronize()
+        out = [tr.step_packed(*xs).clone() for xs in seq]
+        torch.cuda.synchronize()
+        return torch.stack(out), tr.opt_g.flat().data.clone(), tr.opt_d.flat().data.clone()
+    l_list, pg_list, pd_list = run("replay")
+    l_eager, pg_eager, pd_eager = run(False)
+    assert torch.equal(l_list, l_eager) and torch.equal(pg_list, pg_eager) and torch.equal(pd_list, pd_eager)
+
+
 def test_step_marks_follow_the_phases_of_the_step():
     """GanTrainer.marks (tools/step_marks.py): timing events at the phase boundaries of the three-stream step - one set per
     step, in program order on the main stream, D(real) complete before the discriminator's gradients are - and the marked
