@@ -39,7 +39,7 @@ FLOP_PER_TILE = {256: 12.046e9, 512: 48.18e9}      # generator-only forward
 # SURVEY.md 8(d) "algorithmic bytes per img-pair" (ideal fusion: every conv pass touches input, output and weights once, bf16
 # activations, fp32 weight gradients, Adam 28 B/parameter), at the batch per GPU it is quoted for
 BYTES_PER_PAIR = {(256, 16): 237.5e6, (512, 8): 747.3e6}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # rocprofv3 --pmc passes of this workload (tools/pmc_traffic.py)
 
 
 def parse():

@@ -219,8 +219,9 @@ class GanTrainer:
         self.nsteps = 0
         self.use_graph = use_graph
         # second HIP stream: parameter-gradient kernels run under the dgrad/BatchNorm chain, D(real) under G forward
-        self.side = torch.cuda.Stream(device=dev) if overlap else None
-        self.side2 = torch.cuda.Stream(device=dev) if overlap else None
+        sprio = int(_os.environ.get("PFA_SIDE_PRIO", "0"))       # A/B switch: -1 = the side streams at high priority
+        self.side = torch.cuda.Stream(device=dev, priority=sprio) if overlap else None
+        self.side2 = torch.cuda.Stream(device=dev, priority=sprio) if overlap else None
         # optional fourth stream: the generator's weight gradients alternate between `side` and this one (PFA_WGRAD_STREAMS=2)
         self.side3 = torch.cuda.Stream(device=dev) if overlap and WGRAD_STREAMS == 2 else None
         self._ev_real_fwd = torch.cuda.Event() if overlap else None

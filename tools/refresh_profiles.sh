@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write --
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json train_b16_256_bf16 $COMMIT > $O/traffic.txt
 rm -rf $O/pmc_fetch $O/pmc_write
-mkdir -p profiles && cp $O/traffic.json profiles/r03_traffic.json      # (in the box's copy: the bench line below reads it)
+mkdir -p profiles && cp $O/traffic.json profiles/r04_traffic.json      # (in the box's copy: the bench line below reads it)
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 python bench.py --mode infer --batch 64 > $O/bench_infer_b64.json 2> $O/bench_infer.err
 cat $O/traffic.txt
