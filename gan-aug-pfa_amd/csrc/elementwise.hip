@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_bn_act(const T* __restrict__ raw, int64
         for (int e = 0; e < CH; ++e) {
             const float y = x.v[e] * sc[e] + sh[e];
             l.v[e] = y >= 0.f ? y : y * slope;
-            r.v[e] = y > 0.f ? y : (y != y ? y : 0.f);          // (ReLU keeps a NaN, like torch.relu)
+            r.v[e] = y <= 0.f ? 0.f : y;                 // (ReLU keeps a NaN, like torch.relu: the compare is false for it)
         }
         if (out_l) l.store(out_l + idx * CH);
         if (out_r) r.store(out_r + idx * CH);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void k_bn_act_stats(const T* __restrict__ raw,
         for (int e = 0; e < CH; ++e) {
             const float y = x.v[e] * sc[e] + sf[e];
             l.v[e] = y >= 0.f ? y : y * slope;
-            rr.v[e] = y > 0.f ? y : (y != y ? y : 0.f);         // (ReLU keeps a NaN, like torch.relu)
+            rr.v[e] = y <= 0.f ? 0.f : y;                // (ReLU keeps a NaN, like torch.relu: the compare is false for it)
         }
         if (out_l) l.store(out_l + (size_t)r * c + coff);
         if (out_r) rr.store(out_r + (size_t)r * c + coff);

@@ -123,10 +123,15 @@ template <> struct Chunk<bf16_t> {
 // (LeakyReLU: neg = slope, ReLU: 0, none: 1).  A `switch (act)` per element compiles to scalar branches per element - the
 // whole-row epilogues spent most of their time in them; kernels hoist act_neg() out of their element loops.
 __device__ __forceinline__ float act_neg(int act, float slope) { return act == PFA_ACT_LRELU ? slope : act == PFA_ACT_RELU ? 0.f : 1.f; }
-// (neg == 0 selects a literal 0: -inf * 0 would be NaN where torch.relu gives 0 - a bf16 conv output that overflowed must
-// not poison the BatchNorm statistics behind it; the test on `neg` is uniform and hoists with it.  A NaN stays a NaN, as in
-// torch.relu: a diverged run must show it, not train on zeros.)
-__device__ __forceinline__ float act_lin(float v, float neg) { return v > 0.f ? v : (neg != 0.f ? v * neg : (v != v ? v : 0.f)); }
+// Edge cases as torch: a NaN stays a NaN (the compare is false for it: a diverged run must show, not train on zeros);
+// -inf (a bf16 conv output that overflowed) gives -inf under LeakyReLU and 0 under ReLU, where -inf * 0 would be NaN and
+// poison the BatchNorm statistics behind it: the non-positive branch clamps at -FLT_MAX when neg == 0 (the bound is uniform
+// and hoists with neg).  Four VALU operations per element - the whole-row epilogues are VALU-bound: a second compare and
+// select for the NaN case cost the inference forward 8 %.
+__device__ __forceinline__ float act_lin(float v, float neg) {
+    const float lo = neg != 0.f ? -__builtin_inff() : -3.402823466e38f;
+    return v <= 0.f ? fmaxf(v, lo) * neg : v;
+}
 __device__ __forceinline__ float act_grad_lin(float y, float neg) { return y > 0.f ? 1.f : neg; }
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == PFA_ACT_TANH) return tanhf(v);

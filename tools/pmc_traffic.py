@@ -17,7 +17,7 @@ def display(name):
         a = ints(r"k_conv_patch2(?:I|<)([^>E]*(?:E[^>E]*)*)") or ints(r"k_conv_patch2<([^>]*)>")
         a = [x for x in (re.findall(r"(?:Li|<|, ?)(\d+)", name.split("k_conv_patch2")[1][:40]))]
         a = [int(x) for x in a[:3]]
-        return f"k_conv_patch2<{'conv_s2' if a[0] else 'tconv'},{a[1]},{'16x16' if a[2] else '8x32'}>"
+        return f"k_conv_patch2<{'conv_s2' if a[0] else 'tconv'},{a[1]},{('8x32', '16x16', '4x8x8')[a[2]]}>"
     if "k_conv_s1_patch32ILi64" in name or "k_conv_s1_patch32<64" in name:
         return "k_conv_s1_patch<bf16,8x32,64>"
     if "k_conv_s1_inplace" in name:
