@@ -425,8 +425,12 @@ template <int OFF> __device__ __forceinline__ void s1_rd(unsigned addr, bf16x8& 
 }
 constexpr int s1_tap_off(int v) { return ((v >> 2) * PW + (v & 3)) * PSTRIDE; }
 
+// BN: 128 output channels per workgroup, or 64 (FN = 1: the launches whose 128-channel tiles alone would leave half the chip idle -
+// c4's input gradient at batch 16 - run UN-sliced on twice the workgroups: no float32 partial planes, no finish launch)
+template <int BN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k_conv_s1_inplace(const Patch32K q) {
-    constexpr int FN = 2, FM = 2, KS = 4, NR = FN + FM;
+    constexpr int FN = BN / 64, FM = 2, KS = 4, NR = FN + FM;
+    constexpr int WB = BN * 128, WP = BN / 64;               // bytes of a weight stage, its DMA pieces per wave
     const GatherK& p = q.g;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     const int split = wid % p.splitk; wid /= p.splitk;
     const int tx = wid % q.tiles_x; wid /= q.tiles_x;
     const int ty = wid % q.tiles_y, img = wid / q.tiles_y;
-    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * 128;
+    const int oy0 = ty * TY, ox0 = tx * TX, n0 = nt * BN;
     const int c0 = split * q.cper;
     const int nsteps = q.cper * 16;
 
@@ -453,9 +457,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     // issue and wait alike).  Weights first: their latency runs under the patch's address arithmetic.
     const int cs = tid & 7, r0 = tid >> 3;
     const int wg = cs ^ ((r0 >> 1) & 7);
-    unsigned woff[2];
+    unsigned woff[WP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
+    for (int i = 0; i < WP; ++i) woff[i] = (unsigned)(((n0 + r0 + 64 * i) * 16 * q.cin + wg * 8) * 2);
     const unsigned cin2 = (unsigned)q.cin * 2;
     const unsigned tap0 = q.flip ? 15u * cin2 : 0u;              // tap of position V: flip ? 15 - V : V
     const int tapd = q.flip ? -(int)cin2 : (int)cin2;
@@ -464,11 +468,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         char* wb = smem + 2 * PATCH_BYTES + slot_off;
         const unsigned soff = chunk_off + (unsigned)((int)tap0 + V * tapd);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) buf_dma16(p.w, wb + (i * 512 + wave * 64) * 16, woff[i], soff);
+        for (int i = 0; i < WP; ++i) buf_dma16(p.w, wb + (i * 512 + wave * 64) * 16, woff[i], soff);
     };
     unsigned ck_cur = (unsigned)c0 * 128, ck_nxt = q.cper > 1 ? ck_cur + 128 : PFA_DMA_OOB;      // this chunk's and the next one's scalar
     stage_w(ck_cur, std::integral_constant<int, 0>{}, 0);
-    stage_w(ck_cur, std::integral_constant<int, 1>{}, W_BYTES);
+    stage_w(ck_cur, std::integral_constant<int, 1>{}, WB);
     unsigned poff[PPASS];
 #pragma unroll
     for (int j = 0; j < PPASS; ++j) {
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     unsigned wadr[KS];
     {
-        const int row = wn * 64 + lr;
+        const int row = wn * (BN / 2) + lr;
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) wadr[s2] = lds0 + 2 * PATCH_BYTES + row * 128 + (((2 * s2 + lh) ^ ((row >> 1) & 7)) << 4);
     }
@@ -520,22 +524,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     // (slot already added), activation bases ab[]
     auto read_frag = [&](auto v_, auto s2_, auto e_, const unsigned (&ab)[FM], const unsigned (&wv)[KS]) {
         constexpr int V = decltype(v_)::value, S2 = decltype(s2_)::value, E = decltype(e_)::value;
-        if constexpr (E == 0) s1_rd<0>(wv[S2], fw[0][S2]);
-        else if constexpr (E == 1) s1_rd<4096>(wv[S2], fw[1][S2]);
-        else s1_rd<s1_tap_off(V) + S2 * 32>(ab[E - 2], fa[E - 2][S2]);
+        if constexpr (E < FN) s1_rd<E * 4096>(wv[S2], fw[E][S2]);
+        else s1_rd<s1_tap_off(V) + S2 * 32>(ab[E - FN], fa[E - FN][S2]);
     };
     auto read_kstep = [&](auto v_, auto s2_, const unsigned (&ab)[FM], const unsigned (&wv)[KS]) {
-        read_frag(v_, s2_, std::integral_constant<int, 0>{}, ab, wv);
-        read_frag(v_, s2_, std::integral_constant<int, 1>{}, ab, wv);
-        read_frag(v_, s2_, std::integral_constant<int, 2>{}, ab, wv);
-        read_frag(v_, s2_, std::integral_constant<int, 3>{}, ab, wv);
+        [&]<int... E>(std::integer_sequence<int, E...>) {
+            (read_frag(v_, s2_, std::integral_constant<int, E>{}, ab, wv), ...);
+        }(std::make_integer_sequence<int, NR>{});
     };
 
     wait_vmc<0>();
     __builtin_amdgcn_s_barrier();
     unsigned acur[FM] = {abuf[0][0], abuf[0][1]}, aoth[FM] = {abuf[1][0], abuf[1][1]};
     // weight slot offsets of stage i (being computed), i+1 (read ahead during step i), i+2 (filled during step i)
-    unsigned w_cur = 0, w_nxt = W_BYTES, w_fil = 2 * W_BYTES;
+    unsigned w_cur = 0, w_nxt = WB, w_fil = 2 * WB;
     {
         unsigned wv[KS];
 #pragma unroll
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             for (int b = 0; b < FM; ++b) pin(fa[b][S2]);
             __builtin_amdgcn_sched_barrier(0);
             // the k-step's reads and DMA in the shadows of its own MFMAs (see conv_patch2.hip): M(w0,a0) [DMA] M(w1,a0) R(a0)
-            // M(w0,a1) R(w0) M(w1,a1) R(w1) R(a1)
+            // M(w0,a1) R(w0) M(w1,a1) R(w1) R(a1); fragment index: 0 .. FN-1 weight tiles, FN .. activation tiles
             auto mfma = [&](auto a_, auto b_) {
                 constexpr int A = decltype(a_)::value, B = decltype(b_)::value;
                 acc[A][B] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[A][S2], fa[B][S2], acc[A][B], 0, 0, 0);
@@ -583,7 +585,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
             if (S2 == 0) stage_w(V + 2 < 16 ? ck_cur : ck_nxt, std::integral_constant<int, (V + 2) & 15>{}, w_fil);       // stage i+2
             if (S2 == 2 && p_issued) stage_patch_piece(ck_nxt, (chunk + 1) & 1, V < PPASS ? V : 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma(I1{}, I0{}); rd(I2{}); mfma(I0{}, I1{}); rd(I0{}); mfma(I1{}, I1{}); rd(I1{}); rd(I3{});
+            if constexpr (FN == 2) { mfma(I1{}, I0{}); rd(I2{}); mfma(I0{}, I1{}); rd(I0{}); mfma(I1{}, I1{}); rd(I1{}); rd(I3{}); }
+            else { rd(I1{}); mfma(I0{}, I1{}); rd(I0{}); rd(I2{}); }        // (one weight tile: M(w,a0) [DMA] R(a0) M(w,a1) R(w) R(a1))
         };
         kstep(std::integral_constant<int, 0>{});
         kstep(std::integral_constant<int, 1>{});
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
     wait_vmc<0>();                               // (the pieces issued behind the slice's end)
 
-    constexpr int RS = patch_image_stride<128>();
+    constexpr int RS = patch_image_stride<BN>();
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < FM; ++b) {
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
-                *(f32x4*)(row + (wn * 64 + a * 32 + 8 * g + 4 * lh) * 4) = v;
+                *(f32x4*)(row + (wn * (BN / 2) + a * 32 + 8 * g + 4 * lh) * 4) = v;
             }
     }
     __syncthreads();
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void k
         opix = valid ? ((size_t)img * q.hout + oy) * q.wout + ox : 0;
     };
     const size_t trow = ((size_t)img * q.tiles_y + ty) * q.tiles_x + tx;
-    patch_epilogue_rows<128>(p, n0, tid, split, trow, smem, pix_of);
+    patch_epilogue_rows<BN>(p, n0, tid, split, trow, smem, pix_of);
 }
 
 }  // namespace
@@ -676,8 +679,13 @@ bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int sp
     // three-stream step that is faster (round 2: 3.306 vs 3.329 ms; round 3, three same-box pairs: 3.044 vs 3.065 ms), because
     // the other streams use the idle half of the chip; alone on the GPU the launch takes 113 us instead of 60 + 12, which is
     // what a one-stream kernel trace shows.  The timed step decides: 128; 192 restores the K-sliced plan.)
-    if (n % 128 == 0 && (long long)tiles * (n / 128) >= (pfa_knob(10) > 0 ? pfa_knob(10) : (pfa_knob(15) ? 192 : 128))) b = 128;     // knob 15: the launch is alone on the GPU
-    else if ((long long)tiles * (n / 64) >= 192 && pfa_knob(3) == 7) b = 64;          // knob 3 = 7 only: measured slower (below)
+    const int want = pfa_knob(10) > 0 ? pfa_knob(10) : (pfa_knob(15) ? 192 : 128);      // knob 15: the launch is alone on the GPU
+    if (pfa_knob(3) == 7) b = 64;                                 // (tests: 64-channel tiles whenever the geometry fits)
+    else if (n % 128 == 0 && (long long)tiles * (n / 128) >= want) b = 128;
+    // 64-channel tiles on the in-place loop (round 4): where 128-channel tiles would need K slices to fill the chip - c4's input
+    // gradient when it runs alone: 256 un-sliced workgroups, no float32 partial planes (2 x 33.5 MB written and read back), no
+    // finish launch.  (knob 3 = 9: off, the K-sliced plan of round 3.)
+    else if ((long long)tiles * (n / 64) >= 192 && pfa_knob(3) != 9) b = 64;
     else if (n % 128 == 0) {
         b = 128;
         sk = splitk_caller < 1 ? 1 : splitk_caller;
@@ -716,13 +724,15 @@ int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, in
     q.order = pfa_knob(5) == 1 ? 1 : 0;
     q.tiles_y = (q.hout + TY - 1) / TY; q.tiles_x = (q.wout + TX - 1) / TX; q.ntiles = k.n / bn;
     q.nwg = k.nb * q.tiles_y * q.tiles_x * q.ntiles * k.splitk;
-    if (bn == 128 && pfa_knob(3) != 8) {                     // knob 3 = 8: the two-phase loop (A/B)
+    if (pfa_knob(3) != 8) {                                  // knob 3 = 8: the two-phase loop (A/B)
         static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
         if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)k_conv_s1_inplace, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)k_conv_s1_inplace<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            (void)hipFuncSetAttribute((const void*)k_conv_s1_inplace<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
             attr_done = true;
         }
-        hipLaunchKernelGGL(k_conv_s1_inplace, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
+        if (bn == 128) hipLaunchKernelGGL(k_conv_s1_inplace<128>, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
+        else hipLaunchKernelGGL(k_conv_s1_inplace<64>, dim3(q.nwg), dim3(512), LDS_BYTES, st, q);
         PFA_LAUNCHED("k_conv_s1_inplace");
         return 0;
     }

@@ -1013,7 +1013,7 @@ inline bool patch_route(const pfa_gather_args* a, const GatherK& k, int* tiles, 
     } else if (!pfa_conv_s1_plan(grad ? 1 : 0, a->nb, a->hs, a->ws, a->c1, a->n, k.splitk, &bn, &sk, &t)) {
         return false;
     }
-    if (pfa_knob(3) != 2 && (long long)t * (a->n / bn) * sk < 128) return false;
+    if (pfa_knob(3) != 2 && pfa_knob(3) != 7 && (long long)t * (a->n / bn) * sk < 128) return false;
     if (tiles) *tiles = t;
     if (bn_out) *bn_out = bn;
     if (splitk_out) *splitk_out = sk;
@@ -1265,7 +1265,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
                                    a->nb, a->hs, a->ws, a->c1, a->n, st);
         else
             rc = pfa_conv_s1_patch32(a->mode == PFA_CONV_S1_DGRAD ? 1 : 0, kk, pbn, a->hs, a->ws, a->c1, st);
-        g_last_gather_name = pbn != 128 ? "k_conv_s1_patch<bf16,8x32,64>"
+        g_last_gather_name = pbn != 128 ? (pfa_knob(3) == 8 ? "k_conv_s1_patch<bf16,8x32,64>" : "k_conv_s1_inplace<bf16,8x32,64>")
                              : pfa_knob(3) == 6 || pfa_knob(3) == 8 ? "k_conv_s1_patch<bf16,8x32,128>" : "k_conv_s1_inplace<bf16,8x32,128>";
     } else if (image) {
         const char* nm = "";

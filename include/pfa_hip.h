@@ -64,7 +64,8 @@ uint64_t pfa_launch_count(void);
  * convolutions and transposed convolutions): 0 = launches large enough to fill the chip, 1 = never, 2 = whenever the geometry
  * fits, 3 = the stride-1 kernel only, 4 = no four-class transposed workgroups (conv_tconv4.hip), 5 = patch kernels and
  * four-class workgroups whenever the geometry fits, 6 / 8 = the stride-1 kernel's earlier forms (two-phase loop on MFMA
- * 16x16x32 / 32x32x16), 7 = 64-channel tiles for stride-1 launches whose 128-channel tiles leave the chip half empty;
+ * 16x16x32 / 32x32x16), 7 = 64-channel tiles of the stride-1 kernel whenever the geometry fits (tests; by default they are taken where 128-channel tiles
+ * would need K slices to fill the chip), 9 = never (the K-sliced plan of round 3);
  * id 5: gather work-list order over the XCDs (0 = byte-count heuristic, 1..3 = force order 0..2); id 6: minimum number
  * of 256-row tiles for the ring tile, and of workgroups a stride-2 patch launch wants before it narrows its channel tile
  * or slices K (0 = defaults); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined

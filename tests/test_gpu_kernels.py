@@ -136,6 +136,43 @@ PATCH_CASES = [  # name, N, Ci, H, W, Co, K slices
 ]
 
 
+@pytest.mark.parametrize("grad", [False, True], ids=["forward", "input_gradient"])
+def test_conv_s1_inplace_64_channel_tiles(grad, ws):
+    """The stride-1 patch kernel on 64-channel tiles (round 4: c4's input gradient un-sliced on 256 workgroups instead of
+    K-sliced through float32 partial planes; pfa_set_knob(3, 7) takes them for these small shapes): forward and input
+    gradient against the oracle and against the implicit GEMM, ragged tiles, two channel chunks, three 64-channel tiles."""
+    dtype = torch.bfloat16
+    n, ci, h, w, co = 2, 128, 17, 35, 192
+    lib = _lib.lib()
+    if not grad:
+        x = rnd(fill.uniform("s64.x", (n, ci, h, w)), dtype)
+        wt = rnd(fill.uniform("s64.w", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        want = ops.conv2d_fwd(x, wt, None, 1)
+        wsh, _ = shadows(wt, dtype, cparts=[(ci, ci)], want=("same",))
+        src, mode, cout = to_nhwc(x, dtype), K.CONV_S1, co
+    else:
+        x0 = fill.uniform("s64.gx", (n, ci, h, w))
+        wt = rnd(fill.uniform("s64.wg", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        dy = rnd(fill.uniform("s64.dy", (n, co, h - 1, w - 1)), dtype)
+        want, _, _ = ops.conv2d_bwd(x0, wt, dy, 1)
+        _, wsh = shadows(wt, dtype, want=("tr",))
+        src, mode, cout = to_nhwc(dy, dtype), K.CONV_S1_DGRAD, ci
+    ho, wo = want.shape[2:]
+    outs = []
+    for knob in (7, 1):
+        out = torch.full((n, ho, wo, cout), 7.0, dtype=dtype, device="cuda")
+        lib.pfa_set_knob(3, knob)
+        try:
+            K.gather_gemm(mode, [src], wsh, cout, [out], (n, ho, wo), ws)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(3, 0)
+        assert kernel == ("k_conv_s1_inplace<bf16,8x32,64>" if knob == 7 else kernel) and (knob == 7 or kernel.startswith("k_gather_gemm")), kernel
+        outs.append(from_nhwc(out, cout))
+    close(outs[0], want, dtype, "s1 64-channel tiles")
+    close(outs[0], outs[1], dtype, "s1 64-channel tiles vs implicit GEMM", scale=np.abs(want).max())
+
+
 @pytest.mark.parametrize("case", PATCH_CASES, ids=[c[0] for c in PATCH_CASES])
 def test_conv_s1_patch_kernel(case, ws):
     """Stride-1 forward convolutions (the discriminator's c4) take the patch kernel of conv_patch.hip when they are large

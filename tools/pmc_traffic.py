@@ -20,6 +20,8 @@ def display(name):
         return f"k_conv_patch2<{'conv_s2' if a[0] else 'tconv'},{a[1]},{('8x32', '16x16', '4x8x8')[a[2]]}>"
     if "k_conv_s1_patch32ILi64" in name or "k_conv_s1_patch32<64" in name:
         return "k_conv_s1_patch<bf16,8x32,64>"
+    if "k_conv_s1_inplaceILi64E" in name or "k_conv_s1_inplace<64>" in name:
+        return "k_conv_s1_inplace<bf16,8x32,64>"
     if "k_conv_s1_inplace" in name:
         return "k_conv_s1_inplace<bf16,8x32,128>"
     if "k_conv_s1_patch" in name:                                     # (the earlier forms of the 128-channel stride-1 patch kernel)
