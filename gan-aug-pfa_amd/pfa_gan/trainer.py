@@ -524,6 +524,10 @@ class GanTrainer:
             K.wait_stream(torch.cuda.current_stream(), self.side2)      # (the L1 partials were written there, long ago)
         K.loss_finish(self._parts, [(2 * PARTS, 2 * PARTS + self._nparts[2]), (3 * PARTS, 3 * PARTS + self._nparts[3])],
                       self.losses[1:2])
+        # (the running loss sums here too, in front of the waits for the side streams: behind them this 5-us launch sat
+        # between the last update and the next step's first kernel)
+        K.axpy(self.loss_sums, self.losses)
+        self._sums_added = True
         if self.side is not None:
             K.wait_stream(torch.cuda.current_stream(), self.side)
         if bucketed:
@@ -545,7 +549,10 @@ class GanTrainer:
         else:
             self.opt_g.step(grad_scale=1.0 / self.world, graph_safe=graph_safe)
             self.G.refresh_shadows(force=True)
-        K.axpy(self.loss_sums, self.losses)
+        if getattr(self, "_sums_added", False):
+            self._sums_added = False
+        else:
+            K.axpy(self.loss_sums, self.losses)
         if self._solo_default():             # the hint is process-wide library state: a step does not leave it set for whatever
             K.set_solo(False)                # launches next (eval forwards, another trainer); phases set it again
 
