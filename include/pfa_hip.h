@@ -54,7 +54,8 @@ uint64_t pfa_launch_count(void);
  * 4 = 256x128 two-stage / 8 = 256x128 ring where n >= 128, 6 = 128x64 everywhere, 7 = no ring tiles); id 1: in-kernel ablation bits (1 no stores, 2 no statistics, 4 no MFMA, 8 no DMA,
  * 32 ring: a stage's DMA in one burst; 64 fused backward epilogue without its raw / g2 traffic; 128 staggered ring: no LDS fragment reads
  * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set); 1024 the slice-combining passes
- * (k_splitk_finish_vec, pfa_finish_bn_*) wait one round trip per slice, as before round 3);
+ * (k_splitk_finish_vec, pfa_finish_bn_*) wait one round trip per slice, as before round 3; 4096 no four-image tiles for 8 x 8 maps
+ * on the stride-2 / transposed patch kernels (they go back to the implicit GEMM's ring));
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,
@@ -71,7 +72,8 @@ uint64_t pfa_launch_count(void);
  * or slices K (0 = defaults); id 7: 2 = also use the 256x64 ring for 16 < n <= 64, 4 = half-step software-pipelined
  * ring on the 256x128 tile, 5 = ring on the 128x64 tile, 6 / 7 = staggered ring on the 256x128 tile (the two waves of a SIMD
  * in opposite read / MFMA phases; one phase pair per K-step / per 32-wide half), 11..17 = diagnostic instantiations of the
- * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4): results are wrong;
+ * stride-2 patch kernels (conv and weight gradient) without MFMAs (bit 1), fragment reads (2), DMA (4), 18 / 19 = the conv kernel without its
+ * counted vmcnt wait / without that wait and the step's barrier: results are wrong;
  * id 8: workgroups a weight-gradient patch launch wants (0 = 128); id 9: workgroup count from which transposed
  * convolutions take four-class workgroups, id 10: 128-channel tile count below which stride-1 convolutions slice K (0 = 128); id 11: Adam grid (0 = default);
  * id 12: reduction slices the image-side weight gradient (wgrad_image.hip; off with id 4 = 7 | 9) wants (0 = 256);
