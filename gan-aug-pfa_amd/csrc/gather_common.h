@@ -59,6 +59,10 @@ int pfa_conv_patch2(const GatherK& k, const Patch2Plan& plan, hipStream_t st, co
 bool pfa_conv_s1_plan(int grad, int nb, int hin, int win, int cin, int n, int splitk_caller, int* bn, int* splitk, int* stat_tiles);
 int pfa_conv_s1_patch32(int grad, const GatherK& k, int bn, int hin, int win, int cin, hipStream_t st);
 
+// csrc/conv_rows.hip: the implicit GEMM over im2col rows with the patch kernels' K loop (bf16, 64-multiple channel counts)
+bool pfa_conv_rows_ok(const GatherK& k, int dtype);
+int pfa_conv_rows(GatherK k, int classes, int (*order_of)(const GatherK&), hipStream_t st, const char** kernel_name);
+
 // csrc/conv_image.hip: stride-2 convolution of the image-side layers (8-channel sources, 64 outputs)
 bool pfa_conv_image_ok(const GatherK& k, int dtype, int* stat_tiles);
 int pfa_conv_image(const GatherK& k, hipStream_t st, const char** kernel_name);

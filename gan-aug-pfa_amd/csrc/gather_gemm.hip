@@ -1101,6 +1101,16 @@ static int dispatch_gather(const GatherK& k, int classes, int cfg, hipStream_t s
     static const int default_early[] = {2, 0, 1, 1, 1};
     int early = pfa_knob(2) >= 1 && pfa_knob(2) <= 3 ? pfa_knob(2) - 1 : default_early[cfg];
     if ((pfa_knob(0) == 8 || pfa_knob(0) == 0) && cfg == 3 && pfa_knob(2) == 0) early = 2;    // 256x128: the 3-stage ring
+    // round 4, opt-in (knob 1 bit 16384): the launches of the 256-row tile in bf16 on whole 64-channel chunks on the row kernel of
+    // conv_rows.hip (the patch kernels' K loop over gathered rows; measured slower inside the three-stream step)
+    if constexpr (std::is_same_v<T, bf16_t>) {
+        if (cfg == 3 && pfa_knob(0) == 0 && pfa_knob(2) == 0 && pfa_knob(7) == 0 && pfa_conv_rows_ok(k, PFA_BF16)) {
+            const char* nm = "";
+            const int rc = pfa_conv_rows(k, classes, [](const GatherK& kk) { return choose_order(kk); }, st, &nm);
+            g_last_gather_name = nm;
+            return rc;
+        }
+    }
     // (narrow-staging launches on the 128x128 tile keep the spread loop: reads-first measured 40 % slower there)
     switch (cfg * 3 + early) {
         case 0: return launch_gather<T, 128, 128, 2, 2, 0>(k, classes, st);

@@ -462,6 +462,87 @@ def test_ring_loops_of_the_256x128_tile(case, loop, ws):
           scale=np.abs(want).sum(axis=(0, 2, 3)).max())
 
 
+ROWS_CASES = [  # name, kind, N, cin parts, H, W (input), Co, stride, K slices
+    ("e6_like", "conv", 16, [128], 8, 8, 128, 2, 4),             # 256 rows = one tile, 32 K-steps in 4 slices
+    ("e7_like", "conv", 5, [64], 4, 4, 128, 2, 2),               # 20 rows of 256 (2 x 2 maps), taps mostly outside
+    ("one_by_one", "conv", 3, [64], 2, 2, 128, 2, 1),            # 1 x 1 output maps: only the four centre taps see pixels
+    ("d6_like", "tconv", 4, [128, 64], 4, 4, 192, 2, 3),         # four parity classes, virtual concat of unequal widths, 3 column tiles
+    ("d7_like", "tconv", 6, [64], 2, 2, 128, 2, 1),              # 2 x 2 source maps
+    ("s1", "conv", 2, [64], 9, 11, 128, 1, 1),                   # stride 1
+    ("two_row_tiles", "conv", 2, [64, 64], 32, 32, 128, 2, 5),   # 512 rows = two tiles, concat, 32 K-steps in 5 slices of 7 (the last: 4)
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES, ids=[c[0] for c in ROWS_CASES])
+def test_conv_rows_kernel(case, ws):
+    """The implicit GEMM over gathered rows with the patch kernels' K loop (conv_rows.hip, round 4: the small maps of the
+    generator's inner levels and whatever the patch planners turn down; opt-in: knob 1 bit 16384): the oracle, the statistics
+    contract, and the ring tile of k_gather_gemm up to the order of the float32 sums.  pfa_set_knob(6, 1) admits the 256-row
+    tile on launches this small."""
+    name, kind, n, cins, h, w, co, stride, splitk = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".rx", (n, ci, h, w)), dtype)
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    if kind == "conv":
+        wt = rnd(fill.uniform(name + ".rw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+        want = ops.conv2d_fwd(x, wt, None, stride)
+        wsh, _ = shadows(wt, dtype, cparts=[(c, K.pad_ch(c, dtype)) for c in cins], want=("same",))
+        mode, grid = (K.CONV_S2 if stride == 2 else K.CONV_S1), (n,) + want.shape[2:]
+    else:
+        wt = rnd(fill.uniform(name + ".rw", (ci, co, 4, 4), -0.25, 0.25), dtype)
+        want = ops.convT2d_fwd(x, wt, None)
+        _, wsh = shadows(wt, dtype, want=("tr",))
+        mode, grid = K.TCONV_S2, (n, h, w)
+    lib = _lib.lib()
+    res, sums = [], []
+    for knob1, kernel_want in ((16384, "k_conv_rows<bf16,256,64>"), (0, "k_gather_gemm<bf16,256,128,4,2,")):
+        out = torch.full((n,) + want.shape[2:] + (K.pad_ch(co, dtype),), 7.0, dtype=dtype, device="cuda")
+        lib.pfa_set_knob(6, 1)
+        lib.pfa_set_knob(1, knob1)
+        try:
+            st = K.gather_gemm(mode, srcs, wsh, co, [out], grid, ws, stats=True, splitk=splitk)
+            kernel = lib.pfa_last_gather_kernel().decode()
+        finally:
+            lib.pfa_set_knob(6, 0)
+            lib.pfa_set_knob(1, 0)
+        assert kernel.startswith(kernel_want), kernel
+        res.append(from_nhwc(out, co))
+        psum, _, nt = st
+        torch.cuda.synchronize()
+        sums.append(psum[: nt * co].view(nt, co).double().sum(0).cpu().numpy())
+    close(res[0], want, dtype, name)
+    close(res[0], res[1], dtype, name + " vs the ring tile", scale=np.abs(want).max())
+    close(sums[0], want.astype(np.float64).sum(axis=(0, 2, 3)), torch.float32, name + ".psum",
+          scale=np.abs(want).sum(axis=(0, 2, 3)).max())
+
+
+def test_conv_rows_kernel_stride1_input_gradient(ws):
+    """The input gradient of a stride-1 convolution (PFA_CONV_S1_DGRAD: 16 taps walked backwards) on the row kernel."""
+    dtype = torch.bfloat16
+    n, ci, h, w, co, slices = 2, 128, 9, 8, 64, 2
+    x = fill.uniform("rows.gx", (n, ci, h, w))
+    wt = rnd(fill.uniform("rows.gw", (co, ci, 4, 4), -0.25, 0.25), dtype)
+    dy = rnd(fill.uniform("rows.gdy", (n, co, h - 1, w - 1)), dtype)
+    want, _, _ = ops.conv2d_bwd(x, wt, dy, 1)
+    _, tr = shadows(wt, dtype, want=("tr",))
+    lib = _lib.lib()
+    out = torch.full((n, h, w, ci), 7.0, dtype=dtype, device="cuda")
+    lib.pfa_set_knob(6, 1)
+    lib.pfa_set_knob(1, 16384)
+    try:
+        K.gather_gemm(K.CONV_S1_DGRAD, [to_nhwc(dy, dtype)], tr, ci, [out], (n, h, w), ws, splitk=slices)
+        kernel = lib.pfa_last_gather_kernel().decode()
+    finally:
+        lib.pfa_set_knob(6, 0)
+        lib.pfa_set_knob(1, 0)
+    assert kernel == "k_conv_rows<bf16,256,64>", kernel
+    close(from_nhwc(out, ci), want, dtype, "rows s1 dgrad")
+
+
 AFFINE_CASES = [  # name, mode, N, cin parts, H, W, Co, two outputs, K slices
     ("enc_small", "conv", 2, [8], 16, 16, 8, True, 1),             # narrow staging, 256x16 tile
     ("enc_mid", "conv", 2, [64], 32, 32, 96, True, 1),             # 128x128 tile, ragged columns
