@@ -1052,6 +1052,22 @@ extern "C" int pfa_gather_stat_tiles(const pfa_gather_args* a) {
     return classes * ((k.M + bm - 1) / bm);
 }
 
+// Slices pfa_gather_gemm will run this call in (the planners may keep fewer than the caller asked for - down to one, where the
+// tiles alone fill the chip): what a caller that wants to finish the slices itself (PFA_FUSE_DEFER) has to know beforehand.
+extern "C" int pfa_gather_plan_splitk(const pfa_gather_args* a) {
+    GatherK k; int classes;
+    if (int rc = fill_params_geometry(a, k, classes)) return rc;
+    const bool defer = a->fuse_out == PFA_FUSE_DEFER;
+    if (defer) k.fuse_out = 0;
+    int ptiles = 0, pbn = 128, psk = 1;
+    if (!defer && patch_route(a, k, &ptiles, &pbn, &psk)) return psk;
+    int itiles = 0;
+    if (!defer && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles)) return 1;
+    Patch2Plan plan2;
+    if (pfa_conv_patch2_plan(k, a->dtype, &plan2)) return plan2.splitk;     // (one slice: the caller should not defer this launch)
+    return k.splitk;
+}
+
 // Elements each order pulls through the 8 private L2s, to first order (an operand part an XCD needs is fetched by that XCD
 // once; A = input elements, W = weight elements, C = parity classes, S = K slices, P = S*C "planes" of m x n tiles):
 //   order 0 (plane-major): a plane reads the whole input and 1/P of the weights; with P < 8 a plane is cut over 8/P XCDs
@@ -1251,8 +1267,9 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     PFA_REQUIRE(!(a->fuse_out == 1 || a->fuse_out == 2) || (a->fuse_mean != nullptr) == (a->psum != nullptr),
                 "pfa_gather_gemm: a fused BatchNorm backward needs psum/psq, a fused activation backward must not pass them");
     hipStream_t st = (hipStream_t)s;
-    // PFA_FUSE_DEFER: the K slices stay in the slab for a finish of the caller's (pfa_finish_bn_*): the implicit GEMM runs
-    // them (the small maps this is for are its launches anyway)
+    // PFA_FUSE_DEFER: the K slices stay in the slab for a finish of the caller's (pfa_finish_bn_* / pfa_finish_coop_*): the
+    // stride-2 / transposed patch kernel runs them where its plan keeps more than one slice, else the implicit GEMM (with the
+    // caller's slices: pfa_gather_plan_splitk tells beforehand)
     const bool defer = a->fuse_out == PFA_FUSE_DEFER;
     if (defer) k.fuse_out = 0;
     int ptiles = 0, pbn = 128, psk = 1;
@@ -1261,7 +1278,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
     int itiles = 0;
     const bool image = !defer && !patch && k.splitk == 1 && pfa_conv_image_ok(k, a->dtype, &itiles);
     Patch2Plan plan2;
-    const bool patch2 = !defer && !patch && !image && pfa_conv_patch2_plan(k, a->dtype, &plan2);
+    const bool patch2 = !patch && !image && pfa_conv_patch2_plan(k, a->dtype, &plan2) && (!defer || plan2.splitk > 1);
     if (patch2) k.splitk = plan2.splitk;          // never more slices than the caller sized the slab for
     const TileCfg cfg = choose_cfg(k);
     int rc;

@@ -41,7 +41,7 @@ const Entry g_table[] = {
     PFA_ENTRY(pfa_fill_zero), PFA_ENTRY(pfa_axpy), PFA_ENTRY(pfa_finish_bn_fwd), PFA_ENTRY(pfa_finish_bn_bwd),
     PFA_ENTRY(pfa_bce_logits_parts), PFA_ENTRY(pfa_l1_tanh_bwd_parts), PFA_ENTRY(pfa_loss_finish),
     PFA_ENTRY(pfa_bn_act_stats), PFA_ENTRY(pfa_bn_bwd_apply_stats), PFA_ENTRY(pfa_set_knob), PFA_ENTRY(pfa_logit_fwd_bce), PFA_ENTRY(pfa_adam_shadow_batch),
-    PFA_ENTRY(pfa_allreduce),
+    PFA_ENTRY(pfa_allreduce), PFA_ENTRY(pfa_finish_coop_fwd), PFA_ENTRY(pfa_finish_coop_bwd),
 };
 constexpr int g_entries = sizeof(g_table) / sizeof(g_table[0]);
 

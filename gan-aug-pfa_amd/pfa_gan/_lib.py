@@ -138,6 +138,16 @@ PROTOTYPES = {
     "pfa_finish_bn_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_void_p]),
+    "pfa_gather_plan_splitk": (c_int, [POINTER(GatherArgs)]),
+    "pfa_finish_coop_supported": (c_int, [c_int, c_int, c_int]),
+    "pfa_finish_coop_part_floats": (c_size_t, [c_int, c_int]),
+    "pfa_finish_coop_bar_words": (c_size_t, [c_int]),
+    "pfa_finish_coop_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pfa_finish_coop_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "pfa_comm_unique_id": (c_int, [c_void_p, c_int]),
     "pfa_comm_create": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "pfa_comm_destroy": (c_int, [c_void_p]),

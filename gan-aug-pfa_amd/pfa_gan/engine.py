@@ -418,6 +418,17 @@ class _Engine:
                             ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32),
                             ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32))
             return
+        if train and raw.shape[3] == L.cout and K.coop_ok(raw, L.cout):
+            # mid-size map: if the launch is K-sliced, its slices meet in ONE launch on the whole chip (finish_coop.hip) instead
+            # of finish pass + folded BatchNorm pass
+            res = K.gather_gemm(mode, srcs, L.w_fwd, L.cout, [raw], grid, self.ws, defer="try")
+            if res is not None:
+                f32, c = torch.float32, L.cout
+                self.bn_epoch += 1
+                K.finish_coop_fwd(res[0], res[1], c, L.bn, repeats, raw, out_l, out_r,
+                                  ctx.buf(tag + ".scale", (c,), f32), ctx.buf(tag + ".shift", (c,), f32),
+                                  ctx.buf(tag + ".mean", (c,), f32), ctx.buf(tag + ".invstd", (c,), f32), self.ws)
+                return
         st = K.gather_gemm(mode, srcs, L.w_fwd, L.cout, [raw], grid, self.ws, stats=train)
         if train:
             self._bn_act_train(L, ctx, tag, raw, st, count, repeats, out_l, out_r)
@@ -440,6 +451,15 @@ class _Engine:
                             self.flat.seg(garena, bn.weight) if bn is not None and param_grads else None,
                             self.flat.seg(garena, bn.bias) if bn is not None and param_grads else None, dy)
             return dy
+        n1 = outs[0].shape[3] if which == 2 else 0
+        if L.bn is not None and n1 % 64 == 0 and dy.shape[3] == n - n1 and K.coop_ok(dy, n):
+            res = K.gather_gemm(mode, [d], w, n, outs, grid, self.ws_cur, defer="try")
+            if res is not None:
+                bn = L.bn
+                K.finish_coop_bwd(res[0], res[1], n, outs[0] if which == 2 else None, spec, bn.weight,
+                                  self.flat.seg(garena, bn.weight) if param_grads else None,
+                                  self.flat.seg(garena, bn.bias) if param_grads else None, dy, self.ws_cur)
+                return dy
         st = K.gather_gemm(mode, [d], w, n, outs, grid, self.ws_cur, fuse=spec)
         return self._finish_fused(L, ctx, tag, raw, count, garena, dy, st, param_grads=param_grads)
 

@@ -116,6 +116,17 @@ class Workspace:
             self._bufs[name] = buf
         return buf
 
+    def get_zeroed(self, name, numel, dtype=torch.int32):
+        """A buffer that holds zeros when it is created (the library's in-launch meeting counters: every launch leaves them
+        zero again).  Sized once: it is never re-created behind a launch that may still use it."""
+        buf = self._bufs.get(name)
+        if buf is None or buf.numel() < numel or buf.dtype != dtype:
+            if buf is not None:
+                self._retired.append(buf)
+            buf = torch.zeros(max(int(numel), 1), dtype=dtype, device=self.device)
+            self._bufs[name] = buf
+        return buf
+
 
 # ------------------------------------------------------------------------------- gather GEMM
 # Workgroups a K-sliced launch aims for.  In-situ sweeps (bench.py, same box): the training step is fastest at 256 (512 ->
@@ -212,7 +223,8 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
     outs, outs[1] = act2(scale*acc + shift) over the same columns (needs splitk == 1: check auto_splitk first).
     c_real: real (unpadded) contraction channels, for the FLOP accounting of pfa_gather_timing only (0 = as padded).
     defer: run the K slices only (defer_ok must hold) and return (slab, planes): the caller finishes them with
-    finish_bn_fwd / finish_bn_bwd; `outs` then only give the output geometry.
+    finish_bn_fwd / finish_bn_bwd; `outs` then only give the output geometry.  defer="try": the same if the launch will be
+    K-sliced (whichever kernel runs it), else nothing is launched and None is returned (finish_coop_*).
     """
     _require_cuda(*srcs, w, *outs)
     dtype = srcs[0].dtype
@@ -241,6 +253,9 @@ def gather_gemm(mode, srcs, w, n, outs, grid, ws, bias=None, act=ACT_NONE, stats
         a.slab = ptr(slab)
     if defer:
         a.fuse_out = _lib.FUSE_DEFER
+        if defer == "try":          # only if the library will really slice K (its planners may keep one slice): else None
+            if a.splitk <= 1 or lib().pfa_gather_plan_splitk(ctypes.byref(a)) <= 1:
+                return None
         check(lib().pfa_gather_gemm(ctypes.byref(a), stream()), "pfa_gather_gemm")
         return slab, a.splitk
     psum = psq = None
@@ -384,6 +399,60 @@ def finish_bn_bwd(slab, planes, n, plain, fuse, gamma, dgamma, dbeta, dr):
                                   ptr(fuse.get("shift")), ptr(fuse.get("mean")), ptr(fuse.get("invstd")), ptr(gamma),
                                   ptr(dgamma), ptr(dbeta), dt_code(dr.dtype), ptr(dr), dr.shape[3], stream()),
           "pfa_finish_bn_bwd")
+
+
+# Mid-size maps (up to 4096 rows): the same two finishes on up to 256 workgroups that meet once inside the launch
+# (csrc/finish_coop.hip).  OPT-IN (PFA_COOP=1): same-box A/B at B = 16 / 256x256 - the eight launch pairs it replaces per step
+# are 39 us shorter on one stream (+1.1 %), the three-stream step gains +0.2 % (noise): there the GPU is busy with the other
+# streams' workgroups whenever the chain waits, so a shorter chain alone buys nothing, and an in-launch hand-off is not worth
+# carrying in the default path for that.
+COOP = _os.environ.get("PFA_COOP", "0") == "1"
+COOP_BAR_WORDS = 32                    # error flag, epoch, leave counter
+
+
+def coop_ok(t, n):
+    """Can the K slices of a launch whose (fused) output is the bf16 tensor t [B,h,w,n'] be finished by finish_coop_*?"""
+    return (COOP and t.dtype == torch.bfloat16 and rows_of(t) > FINISH_BN_ROWS and
+            bool(lib().pfa_finish_coop_supported(dt_code(t.dtype), rows_of(t), n)))
+
+
+def _coop_ws(ws, rows, n):
+    part = ws.get_zeroed("coop_part", max(lib().pfa_finish_coop_part_floats(rows, n), 1 << 18), torch.float32)   # (tag 0 is never an epoch)
+    bar = ws.get_zeroed("coop_bar", COOP_BAR_WORDS)
+    if lib().pfa_finish_coop_bar_words(n) > bar.numel():
+        raise _lib.PfaError("finish_coop: more columns than the counter block was sized for")
+    return part, bar
+
+
+def coop_gave_up(ws):
+    """Did a finish_coop launch on this workspace give up waiting for its partners (synchronises)?  Its results are garbage."""
+    bar = ws._bufs.get("coop_bar")
+    return bar is not None and int(bar[0].item()) != 0
+
+
+def finish_coop_fwd(slab, planes, n, bn, repeats, raw, out_l, out_r, scale, shift, mean, invstd, ws):
+    """finish_bn_fwd for up to 4096 rows, n % 64 == 0 (see pfa_hip.h); ws: the Workspace of the calling stream."""
+    rows = rows_of(raw)
+    track = bn.track_running_stats and bn.running_mean is not None
+    part, bar = _coop_ws(ws, rows, n)
+    check(lib().pfa_finish_coop_fwd(ptr(slab), planes, rows, n, ptr(bn.weight), ptr(bn.bias), BN_EPS, BN_MOMENTUM,
+                                    repeats if track else 0,
+                                    ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                    ptr(bn.num_batches_tracked) if track else None, dt_code(raw.dtype), ptr(raw), raw.shape[3],
+                                    ptr(out_l), ptr(out_r), SLOPE, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(part),
+                                    ptr(bar), stream()), "pfa_finish_coop_fwd")
+
+
+def finish_coop_bwd(slab, planes, n, plain, fuse, gamma, dgamma, dbeta, dr, ws):
+    """finish_bn_bwd for up to 4096 rows (the fused node carries a BatchNorm; n1 % 64 == 0)."""
+    rows = rows_of(dr)
+    n1 = plain.shape[3] if plain is not None else 0
+    part, bar = _coop_ws(ws, rows, n)
+    check(lib().pfa_finish_coop_bwd(ptr(slab), planes, rows, n, n1, ptr(plain), n1, ptr(fuse["raw"]), ptr(fuse.get("g2")),
+                                    fuse["act1"], fuse.get("act2", ACT_NONE), SLOPE, ptr(fuse.get("scale")),
+                                    ptr(fuse.get("shift")), ptr(fuse.get("mean")), ptr(fuse.get("invstd")), ptr(gamma),
+                                    ptr(dgamma), ptr(dbeta), dt_code(dr.dtype), ptr(dr), dr.shape[3], ptr(part), ptr(bar),
+                                    stream()), "pfa_finish_coop_bwd")
 
 
 # ------------------------------------------------------------------------------- the PatchGAN logit layer

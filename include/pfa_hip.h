@@ -417,6 +417,28 @@ int pfa_finish_bn_bwd(const float* slab, int splitk, int rows, int n, int n1, vo
                       const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, int dtype,
                       void* dr, int ld2, pfa_stream s);
 
+/* The same two finishes for the mid-size maps (up to 4096 rows, n %% 64 == 0: the generator's 8 x 8 and 16 x 16 levels at
+ * batch 16), on up to 256 workgroups that meet once inside the launch (csrc/finish_coop.hip: partial sums as write-through
+ * {epoch, value} granules, a BOUNDED wait).  Same arguments and results as pfa_finish_bn_fwd / _bwd (the statistics are
+ * summed per block of 32-128 rows, then over the blocks; _bwd needs the node's BatchNorm, i.e. mean and invstd, and
+ * n1 %% 64 == 0) plus two caller-owned workspaces: `part` (pfa_finish_coop_part_floats floats, 8-byte aligned) and `bar`
+ * (pfa_finish_coop_bar_words 32-bit words), BOTH ZERO before the first launch that uses them (bar: word 0 is raised if a
+ * launch gave up waiting - its results are then garbage; word 1 counts the launches).  A workspace serves one stream at a
+ * time.  pfa_gather_plan_splitk: the slices pfa_gather_gemm will run the call in (the planners may keep fewer than asked
+ * for; <= 1: nothing to finish, do not defer). */
+int pfa_gather_plan_splitk(const pfa_gather_args* a);
+int pfa_finish_coop_supported(int dtype, int rows, int n);
+size_t pfa_finish_coop_part_floats(int rows, int n);
+size_t pfa_finish_coop_bar_words(int n);
+int pfa_finish_coop_fwd(const float* slab, int splitk, int rows, int n, const float* gamma, const float* beta, float eps,
+                        float momentum, int repeats, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        int dtype, void* raw, int ld, void* out_l, void* out_r, float slope, float* scale, float* shift,
+                        float* mean, float* invstd, float* part, uint32_t* bar, pfa_stream s);
+int pfa_finish_coop_bwd(const float* slab, int splitk, int rows, int n, int n1, void* plain, int ld1, const void* raw,
+                        const void* g2, int act1, int act2, float slope, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, int dtype,
+                        void* dr, int ld2, float* part, uint32_t* bar, pfa_stream s);
+
 /* ------------------------------------------------------------------ data-parallel exchange (one process per GPU)
  * Replaces, for this path, the gradient all-reduce DistributedDataParallel runs behind loss.backward()
  * (/root/reference/train_gan.py:62-63,70-71 under a torch.distributed launcher; BASELINE config 3): an RCCL communicator

@@ -1351,6 +1351,25 @@ def test_whole_batch_finish_forward(case, ws):
     """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_bn_fwd: K-slice combine, BatchNorm training forward (statistics, running
     buffers x2, coefficients for the backward) and both activations in one launch - against the oracle's conv + BatchNorm,
     and against the three-launch route (finish pass, bn_finalize, bn_act)."""
+    _finish_forward(case, ws, coop=False)
+
+
+FINISH_COOP_CASES = [  # name, mode, N, cin parts, H, W (input), Co (a multiple of 64)
+    ("e5_like", "conv", 16, [128], 16, 16, 128),         # 8x8 maps at B = 16: 1024 rows, one row pass, 32 row blocks x 2 groups
+    ("d5_like", "tconv", 4, [64, 64], 16, 16, 64),       # 32x32 outputs: 4096 rows, four row passes per thread
+    ("ragged", "conv", 3, [64], 12, 20, 64),             # 6x10 maps: 180 rows, the last row block is partly empty
+    ("two_passes", "tconv", 3, [128], 13, 13, 128),      # 26x26 outputs: 2028 rows, two passes, ragged
+]
+
+
+@pytest.mark.parametrize("case", FINISH_COOP_CASES, ids=[c[0] for c in FINISH_COOP_CASES])
+def test_meeting_finish_forward(case, ws):
+    """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_coop_fwd (the workgroups of a 64-column group meet once inside the launch):
+    the same checks as the whole-batch finish, the counters left zero, no launch gave up."""
+    _finish_forward(case, ws, coop=True)
+
+
+def _finish_forward(case, ws, coop):
     name, kind, n, cins, h, w, co = case
     dtype = torch.bfloat16
     ci = sum(cins)
@@ -1371,8 +1390,11 @@ def test_whole_batch_finish_forward(case, ws):
     for c in cins:
         srcs.append(to_nhwc(x[:, o:o + c], dtype))
         o += c
-    assert K.defer_ok(mode, srcs, co, grid, rows) == (rows <= K.FINISH_BN_ROWS)      # the engine's threshold; the kernels take more
-    assert _lib.lib().pfa_finish_bn_supported(K.dt_code(dtype), rows, co)
+    if coop:
+        assert _lib.lib().pfa_finish_coop_supported(K.dt_code(dtype), rows, co)
+    else:
+        assert K.defer_ok(mode, srcs, co, grid, rows) == (rows <= K.FINISH_BN_ROWS)      # the engine's threshold; the kernels take more
+        assert _lib.lib().pfa_finish_bn_supported(K.dt_code(dtype), rows, co)
     bn = torch.nn.BatchNorm2d(co).cuda()
     g, b = fill.uniform(name + ".bg", (co,), 0.5, 1.5), fill.uniform(name + ".bb", (co,), -0.5, 0.5)
     rm0, rv0 = fill.uniform(name + ".brm", (co,)), fill.uniform(name + ".brv", (co,), 0.5, 2.0)
@@ -1389,9 +1411,14 @@ def test_whole_batch_finish_forward(case, ws):
     before = _lib.launch_count()
     slab, planes = K.gather_gemm(mode, srcs, wsh, co, [t_raw], grid, ws, defer=True)
     assert planes > 1
-    K.finish_bn_fwd(slab, planes, co, bn, 2, t_raw, t_l, t_r, scale, shift, mean, invstd)
+    if coop:
+        K.finish_coop_fwd(slab, planes, co, bn, 2, t_raw, t_l, t_r, scale, shift, mean, invstd, ws)
+    else:
+        K.finish_bn_fwd(slab, planes, co, bn, 2, t_raw, t_l, t_r, scale, shift, mean, invstd)
     assert _lib.launch_count() - before == 2
     torch.cuda.synchronize()
+    if coop:
+        assert not K.coop_gave_up(ws) and int(ws._bufs["coop_bar"][2]) == 0
     amax = np.abs(raw).max()
     close(from_nhwc(t_raw, co), raw, dtype, name + ".raw", scale=amax)
     close(mean.cpu().numpy(), raw.astype(np.float64).mean(axis=(0, 2, 3)), torch.float32, name + ".mean", scale=amax)
@@ -1415,7 +1442,10 @@ def test_whole_batch_finish_forward(case, ws):
                   sc2, sh2, mu2, is2, repeats=2)
     K.bn_act(u_raw, sc2, sh2, u_l, u_r)
     torch.cuda.synchronize()
-    assert torch.equal(u_raw, t_raw)                                     # same slices, same ascending combine
+    if coop:        # (the un-deferred launch may run on another kernel with other slices)
+        close(from_nhwc(t_raw, co), from_nhwc(u_raw, co), dtype, name + ".raw vs 3 launches", scale=amax)
+    else:
+        assert torch.equal(u_raw, t_raw)                                 # same slices, same ascending combine
     close(scale.cpu().numpy(), sc2.cpu().numpy(), torch.float32, name + ".scale vs 3 launches")
     close(shift.cpu().numpy(), sh2.cpu().numpy(), torch.float32, name + ".shift vs 3 launches", scale=np.abs(sh2.cpu().numpy()).max() + 1)
     close(from_nhwc(t_l, co), from_nhwc(u_l, co), dtype, name + ".lrelu vs 3 launches", scale=np.abs(yy).max())
@@ -1434,6 +1464,24 @@ FINISH_BWD_CASES = [  # name, N, cin, H, W, Co, BatchNorm, second gradient, two 
 def test_whole_batch_finish_backward(case, ws):
     """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_bn_bwd: K-slice combine, dy = LeakyReLU'(y) g (+ ReLU'(y) g2) and the
     BatchNorm backward of dy (dgamma, dbeta accumulated) in one launch, against the oracle."""
+    _finish_backward(case, ws, coop=False)
+
+
+FINISH_COOP_BWD_CASES = [  # name, N, cin, H, W, Co, BatchNorm, second gradient, two outputs
+    ("bn", 16, [64], 16, 16, 64, True, False, False),                # 1024 rows
+    ("bn_g2_ragged", 3, [128], 12, 20, 64, True, True, False),       # 180 rows
+    ("two_outputs", 4, [64], 32, 32, 128, True, False, True),        # [plain 64 | fused 64], 1024 rows: the decoder's input gradient
+    ("many_rows", 16, [64], 32, 32, 64, True, True, False),          # 4096 rows: four row passes
+]
+
+
+@pytest.mark.parametrize("case", FINISH_COOP_BWD_CASES, ids=[c[0] for c in FINISH_COOP_BWD_CASES])
+def test_meeting_finish_backward(case, ws):
+    """pfa_gather_gemm(PFA_FUSE_DEFER) + pfa_finish_coop_bwd, against the oracle; the counters left zero, no launch gave up."""
+    _finish_backward(case, ws, coop=True)
+
+
+def _finish_backward(case, ws, coop):
     name, n, cins, h, w, co, bn, with_g2, two = case
     dtype = torch.bfloat16
     ci = sum(cins)
@@ -1444,7 +1492,8 @@ def test_whole_batch_finish_backward(case, ws):
     rows = n * ho * wo
     wsh, _ = shadows(wt, dtype, want=("same",))
     srcs = [to_nhwc(x, dtype)]
-    assert K.defer_ok(K.CONV_S2, srcs, co, (n, ho, wo), rows) == (rows <= K.FINISH_BN_ROWS)
+    if not coop:
+        assert K.defer_ok(K.CONV_S2, srcs, co, (n, ho, wo), rows) == (rows <= K.FINISH_BN_ROWS)
     c0 = co // 2 if two else 0
     cf = co - c0
     raw = rnd(fill.uniform(name + ".wraw", (n, cf, ho, wo), -1.0, 1.0), dtype)
@@ -1474,15 +1523,54 @@ def test_whole_batch_finish_backward(case, ws):
     dgamma, dbeta = torch.full((cf,), 0.5, device="cuda"), torch.full((cf,), 0.25, device="cuda")
     before = _lib.launch_count()
     slab, planes = K.gather_gemm(K.CONV_S2, srcs, wsh, co, [plain, dr] if two else [dr], (n, ho, wo), ws, defer=True)
-    K.finish_bn_bwd(slab, planes, co, plain, spec, dev(gam) if bn else None, dgamma if bn else None, dbeta if bn else None, dr)
+    if coop:
+        K.finish_coop_bwd(slab, planes, co, plain, spec, dev(gam), dgamma, dbeta, dr, ws)
+    else:
+        K.finish_bn_bwd(slab, planes, co, plain, spec, dev(gam) if bn else None, dgamma if bn else None, dbeta if bn else None, dr)
     assert _lib.launch_count() - before == 2 and planes > 1
     torch.cuda.synchronize()
+    if coop:
+        assert not K.coop_gave_up(ws) and int(ws._bufs["coop_bar"][2]) == 0
     close(from_nhwc(dr, cf), want, dtype, name + ".dr", scale=np.abs(want).max())
     if two:
         close(from_nhwc(plain, c0), g[:, :c0], dtype, name + ".plain", scale=np.abs(g).max())
     if bn:
         close((dgamma - 0.5).cpu().numpy(), dg_ref, dtype, name + ".dgamma", scale=np.abs(dg_ref).max())
         close((dbeta - 0.25).cpu().numpy(), db_ref, dtype, name + ".dbeta", scale=np.abs(db_ref).max())
+
+
+def test_meeting_finish_under_uneven_load(ws):
+    """The in-launch meeting of pfa_finish_coop_fwd must not depend on placement, timing or what the caches hold: the same
+    launch repeated while another stream keeps the chip unevenly busy (GEMMs of changing size), its inputs and partial sums
+    pre-read (L1 / L2 warm), gives the same bits every time; no launch gives up, the counters return to zero."""
+    dtype = torch.bfloat16
+    rows, co, planes = 4096, 512, 4
+    g = torch.Generator(device="cuda").manual_seed(5)
+    slab = torch.randn((planes, rows, co), device="cuda", generator=g)
+    bn = torch.nn.BatchNorm2d(co).cuda()
+    shape = (16, 16, 16, co)
+    outs = [tuple(torch.empty(shape, dtype=dtype, device="cuda") for _ in range(3)) for _ in range(2)]
+    coef = [tuple(torch.empty(co, device="cuda") for _ in range(4)) for _ in range(2)]
+    side = torch.cuda.Stream()
+    a = torch.randn((4096, 4096), device="cuda", dtype=dtype)
+    K.finish_coop_fwd(slab, planes, co, bn, 0, *outs[0], *coef[0], ws)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in outs[0]] + [t.clone() for t in coef[0]]
+    for it in range(40):
+        with torch.cuda.stream(side):
+            for k in range(1 + it % 4):
+                m = 512 << (it + k) % 4
+                torch.mm(a[:m], a)
+        part = ws._bufs["coop_part"]
+        part.sum()                                   # the granules of the previous launch, read by plain loads
+        o, c = outs[it & 1], coef[it & 1]
+        K.finish_coop_fwd(slab, planes, co, bn, 0, *o, *c, ws)
+        if it % 8 == 7:
+            torch.cuda.synchronize()
+            for t, r in zip(list(o) + list(c), ref):
+                assert torch.equal(t, r), it
+    torch.cuda.synchronize()
+    assert not K.coop_gave_up(ws) and int(ws._bufs["coop_bar"][2]) == 0
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)

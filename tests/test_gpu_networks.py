@@ -941,6 +941,44 @@ def test_config2_step_on_16_copies_equals_step_on_one_pair(precision):
                 assert off < (0.02 if precision == "fp32" else 0.10), f"{who} {k}: {off:.2%} of the parameters moved differently"
 
 
+def test_config2_step_with_the_meeting_finish_equals_step_on_one_pair(monkeypatch):
+    """PFA_COOP=1 (kernels.COOP): the generator's 8x8 and 16x16 levels finish their K slices in one launch whose workgroups
+    meet inside it (csrc/finish_coop.hip), forward and backward.  The bench configuration with it on, pinned like the default
+    route: 16 copies of one pair against that pair's B = 1 step (which the oracle test covers)."""
+    gst = fill.fill_state(nets.g_state_shapes(), seed=31, bn_noise=False)
+    dst = fill.fill_state(nets.d_state_shapes(), seed=32, bn_noise=False)
+    a1 = fill.uniform("copies.a", (1, 3, 256, 256))
+    b1 = fill.uniform("copies.b", (1, 3, 256, 256))
+    l1, f1, g1, d1 = _one_step("bf16", a1, b1, gst, dst)
+    monkeypatch.setattr(pfa_gan.kernels, "COOP", True)
+    before = _lib.launch_count()
+    l16, f16, g16, d16 = _one_step("bf16", np.repeat(a1, 16, 0), np.repeat(b1, 16, 0), gst, dst)
+    with_coop = _lib.launch_count() - before
+    monkeypatch.setattr(pfa_gan.kernels, "COOP", False)
+    before = _lib.launch_count()
+    m16 = _one_step("bf16", np.repeat(a1, 16, 0), np.repeat(b1, 16, 0), gst, dst)
+    without = _lib.launch_count() - before
+    assert with_coop <= without - 6, (with_coop, without)        # the launch pairs it folds (four forward, at least two backward)
+    assert_close(l16[0], l1[0], 0, 1e-2, "loss_d")
+    assert_close(l16[1], l1[1], 0, 1e-2, "loss_g")
+    assert_close(l16[0], m16[0][0], 0, 2e-3, "loss_d vs the two-launch route")
+    assert_close(l16[1], m16[0][1], 0, 2e-3, "loss_g vs the two-launch route")
+    assert np.abs(f16 - f16[:1]).max() == 0.0, "the 16 copies must produce one and the same fake image"
+    assert np.abs(f16[:1] - f1).mean() < 1e-2
+    lr = 1e-4
+    for got, want, who in ((g16, g1, "G"), (d16, d1, "D")):
+        for k, v in want.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(got[k]) == int(v), k
+            elif k.endswith("running_var"):
+                continue
+            elif k.endswith("running_mean"):
+                assert_close(got[k], v, 2e-2, 1e-2, f"{who} {k}")
+            else:
+                off = np.mean(np.abs(got[k] - v) > 0.2 * lr)
+                assert off < 0.10, f"{who} {k}: {off:.2%} of the parameters moved differently"
+
+
 def test_512_forward_fp32_vs_reference(golden):
     """BASELINE config 4's tile size: default networks at 512x512 against the reference's forward (tests/golden/full512.npz):
     every map twice as wide as at 256x256, the discriminator's logit map 62x62 (stride-1 patch kernel tiled in x)."""

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
 import torch
 from pfa_gan import kernels as K, _lib
-B = 16
+B = int(os.environ.get("PFA_B", "16"))
 dt = torch.bfloat16
 ws = K.Workspace(torch.device('cuda'))
 def T(*shape): return torch.randn(shape, device='cuda', dtype=torch.float32).to(dt)
