@@ -65,6 +65,8 @@ def parse():
                     help="N > 1: the gradient all-reduces carry bfloat16 (GanTrainer(grad_payload='bf16')); default float32")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)      # former default spelling, accepted
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no wgrad / D(real) overlap")
+    ap.add_argument("--plan-shared", action="store_true",
+                    help="with --no-overlap: keep the launch plans of the three-stream step (profiles of the timed configuration's kernels)")
     ap.add_argument("--no-early-real", action="store_true",
                     help="D(real) of a step waits for the whole previous step (A/B switch for inputs_resident)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,8 +153,9 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     import torch
     from pfa_gan import _lib
     lib = _lib.lib()
-    was_graph, was_side, was_side2 = trainer.use_graph, trainer.side, trainer.side2
+    was_graph, was_side, was_side2, was_plan = trainer.use_graph, trainer.side, trainer.side2, trainer.plan_shared
     trainer.use_graph, trainer.side, trainer.side2 = False, None, None   # one stream: nothing shares the GPU with a timed launch
+    trainer.plan_shared = was_side is not None                           # ... and every launch keeps the plan it has in the timed step
     lib.pfa_gather_timing(1)
     try:
         for _ in range(steps):
@@ -160,14 +163,14 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
         torch.cuda.synchronize()
     finally:
         lib.pfa_gather_timing(0)
-        trainer.use_graph, trainer.side, trainer.side2 = was_graph, was_side, was_side2
+        trainer.use_graph, trainer.side, trainer.side2, trainer.plan_shared = was_graph, was_side, was_side2, was_plan
     per = _timed_kernels(lib, _lib)
     peak = PEAK_BF16_TFLOPS if precision == "bf16" else PEAK_F32_TFLOPS
     unit = FLOP_PER_PAIR.get(xa.shape[1], 0) * xa.shape[0]
     roof = _roofline_object(per, steps, peak, unit, f"train_b{xa.shape[0]}_{xa.shape[1]}_{precision}")
-    roof["mode"] = ("one HIP stream: every launch alone on the GPU (launch plans for a GPU of its own: the stride-1 input "
-                    "gradients K-sliced); in the timed three-stream step the launches that share the GPU with other streams "
-                    "take the plans tuned for sharing (e.g. two of c4's three input gradients un-sliced, no partial planes)")
+    roof["mode"] = ("one HIP stream: every launch alone on the GPU, with the launch plan it has in the timed three-stream step "
+                    "(e.g. c4's input gradient K-sliced on 128-channel tiles in the D phase, where it shares the GPU, and "
+                    "un-sliced on 64-channel tiles in the generator phase, where it runs alone)")
     return roof
 
 
@@ -537,6 +540,8 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if args.plan_shared:
+        trainer.plan_shared = True
     launches0 = _lib.launch_count()
     if os.environ.get("PFA_MAIN_HIGH"):              # A/B switch: the step's main stream at high priority (side streams: normal)
         hp = torch.cuda.Stream(priority=-1)

@@ -238,6 +238,7 @@ class GanTrainer:
         self._ev_static = torch.cuda.Event() if overlap else None      # the static input copies of a replayed step are complete
         self._static = None
         self._graph_one_stream = False
+        self.plan_shared = os.environ.get("PFA_PLAN_SHARED") == "1"
         self.G.refresh_shadows(force=True)
         self.Dn.refresh_shadows(force=True)
 
@@ -368,7 +369,9 @@ class GanTrainer:
         K.loss_finish(parts, [(0, self._nparts[0]), (PARTS, PARTS + self._nparts[1])], self.losses[0:1])
 
     def _solo_default(self):
-        return self.side is None and not self._graph_one_stream
+        # plan_shared (PFA_PLAN_SHARED=1): a one-stream run that keeps the launch plans of the three-stream step - what the
+        # bench's roofline pass and the one-stream profiles measure (the kernels of the TIMED configuration, each alone on the GPU)
+        return self.side is None and not self._graph_one_stream and not self.plan_shared
 
     def _d_forward_bce(self, srcs, ctx, slot, target, lscale, gscale):
         """Discriminator forward + BCE-with-logits (loss partials into slot `slot` of self._parts, dlogits into the context):

@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/p3 $O/p1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p3 -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-roofline --no-extras > $O/p3.json 2> $O/p3.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline --no-extras > $O/p1.json 2> $O/p1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python $R/bench.py --steps 5 --warmup 2 --repeats 1 --no-overlap --plan-shared --no-cpu-baseline --no-roofline --no-extras > $O/p1.json 2> $O/p1.err
 cd $R
 python tools/prof_summary.py $O/p3 7 > $O/p3_summary.txt
 python tools/prof_summary.py $O/p1 7 > $O/p1_summary.txt

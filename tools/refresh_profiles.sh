@@ -15,8 +15,8 @@ mkdir -p $O
 bash $R/tools/prof_step.sh $TAG > $O/prof_step.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/pmc_fetch $O/pmc_write
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline --no-extras > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --no-cpu-baseline --no-roofline --no-extras > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --plan-shared --no-cpu-baseline --no-roofline --no-extras > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 3 --warmup 1 --repeats 1 --no-overlap --plan-shared --no-cpu-baseline --no-roofline --no-extras > /dev/null 2> $O/pmc_write.err
 cd $R
 python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/traffic.json train_b16_256_bf16 $COMMIT > $O/traffic.txt
 rm -rf $O/pmc_fetch $O/pmc_write
