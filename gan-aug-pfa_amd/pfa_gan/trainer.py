@@ -238,7 +238,7 @@ class GanTrainer:
         self._ev_static = torch.cuda.Event() if overlap else None      # the static input copies of a replayed step are complete
         self._static = None
         self._graph_one_stream = False
-        self.plan_shared = os.environ.get("PFA_PLAN_SHARED") == "1"
+        self.plan_shared = _os.environ.get("PFA_PLAN_SHARED") == "1"
         self.G.refresh_shadows(force=True)
         self.Dn.refresh_shadows(force=True)
 
