@@ -112,7 +112,13 @@ def _timed_kernels(lib, _lib):
                                              ctypes.byref(sk)), "pfa_gather_timing_get")
         r = per.setdefault(name.value.decode(), [0.0, 0.0, 0.0, 0, 0])
         r[0] += ms.value; r[1] += flop.value; r[2] += byts.value; r[3] += 1; r[4] += sk.value > 1
+        # the launches of one kernel by operand shape (forward and input-gradient launches of a layer share the kernel)
+        sh = _SHAPES.setdefault(name.value.decode(), {}).setdefault((round(flop.value), round(byts.value), sk.value), [0.0, 0])
+        sh[0] += ms.value; sh[1] += 1
     return per
+
+
+_SHAPES = {}
 
 
 def _roofline_object(per, steps, peak, unit_flop_total, workload_key):
@@ -134,7 +140,11 @@ def _roofline_object(per, steps, peak, unit_flop_total, workload_key):
                    flop_share_of_step=round(v[1] / steps / unit_flop_total, 3) if unit_flop_total else None,
                    share_of_mfma_kernel_time=round(v[0] / total_ms, 3))
               for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])]
+    shapes = [dict(launches_per_step=c // steps, avg_launch_us=round(1e3 * ms / c, 2), flop_per_launch=fl, algorithmic_bytes=by,
+                   k_slices=sk, achieved=round(fl / (ms / c * 1e-3) / 1e12, 2), frac=round(fl / (ms / c * 1e-3) / 1e12 / peak, 4))
+              for (fl, by, sk), (ms, c) in sorted(_SHAPES.get(kernel, {}).items(), key=lambda kv: -kv[1][0])]
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                launch_shapes=shapes,
                 traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(tbytes / n),
                 kernel=kernel, launches_per_step=n // steps, sliced_launches_per_step=nsplit // steps,
                 avg_launch_us=round(1e3 * tms / n, 2), flop_per_launch=round(tflop / n),
@@ -157,6 +167,7 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     trainer.use_graph, trainer.side, trainer.side2 = False, None, None   # one stream: nothing shares the GPU with a timed launch
     trainer.plan_shared = was_side is not None                           # ... and every launch keeps the plan it has in the timed step
     lib.pfa_gather_timing(1)
+    _SHAPES.clear()
     try:
         for _ in range(steps):
             trainer.step_packed(xa, xb)
@@ -170,7 +181,10 @@ def kernel_roofline(trainer, xa, xb, steps, precision):
     roof = _roofline_object(per, steps, peak, unit, f"train_b{xa.shape[0]}_{xa.shape[1]}_{precision}")
     roof["mode"] = ("one HIP stream: every launch alone on the GPU, with the launch plan it has in the timed three-stream step "
                     "(e.g. c4's input gradient K-sliced on 128-channel tiles in the D phase, where it shares the GPU, and "
-                    "un-sliced on 64-channel tiles in the generator phase, where it runs alone)")
+                    "un-sliced on 64-channel tiles in the generator phase, where it runs alone).  launch_shapes: the dominant "
+                    "kernel's launches by operand shape - in the default workload c4's forward (256 workgroups, the whole chip) "
+                    "and its D-phase input gradient (128 workgroups of twice the K: half the chip by plan, the weight "
+                    "gradients of the other streams take the rest); `achieved` averages over both as rocprofv3 --stats does")
     return roof
 
 
