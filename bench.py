@@ -107,13 +107,15 @@ def _timed_kernels(lib, _lib):
     import ctypes
     per = {}
     ms, name, flop, byts, sk = ctypes.c_float(), ctypes.c_char_p(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    nwg = ctypes.c_int()
     for i in range(lib.pfa_gather_timing_count()):
         _lib.check(lib.pfa_gather_timing_get(i, ctypes.byref(ms), ctypes.byref(name), ctypes.byref(flop), ctypes.byref(byts),
                                              ctypes.byref(sk)), "pfa_gather_timing_get")
+        _lib.check(lib.pfa_gather_timing_grid(i, ctypes.byref(nwg)), "pfa_gather_timing_grid")
         r = per.setdefault(name.value.decode(), [0.0, 0.0, 0.0, 0, 0])
         r[0] += ms.value; r[1] += flop.value; r[2] += byts.value; r[3] += 1; r[4] += sk.value > 1
         # the launches of one kernel by operand shape (forward and input-gradient launches of a layer share the kernel)
-        sh = _SHAPES.setdefault(name.value.decode(), {}).setdefault((round(flop.value), round(byts.value), sk.value), [0.0, 0])
+        sh = _SHAPES.setdefault(name.value.decode(), {}).setdefault((round(flop.value), round(byts.value), sk.value, nwg.value), [0.0, 0])
         sh[0] += ms.value; sh[1] += 1
     return per
 
@@ -140,9 +142,14 @@ def _roofline_object(per, steps, peak, unit_flop_total, workload_key):
                    flop_share_of_step=round(v[1] / steps / unit_flop_total, 3) if unit_flop_total else None,
                    share_of_mfma_kernel_time=round(v[0] / total_ms, 3))
               for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])]
-    shapes = [dict(launches_per_step=c // steps, avg_launch_us=round(1e3 * ms / c, 2), flop_per_launch=fl, algorithmic_bytes=by,
-                   k_slices=sk, achieved=round(fl / (ms / c * 1e-3) / 1e12, 2), frac=round(fl / (ms / c * 1e-3) / 1e12 / peak, 4))
-              for (fl, by, sk), (ms, c) in sorted(_SHAPES.get(kernel, {}).items(), key=lambda kv: -kv[1][0])]
+    shapes = []
+    for (fl, by, sk, wg), (ms, c) in sorted(_SHAPES.get(kernel, {}).items(), key=lambda kv: -kv[1][0]):
+        ach = fl / (ms / c * 1e-3) / 1e12
+        e = dict(launches_per_step=c // steps, workgroups=wg or None, avg_launch_us=round(1e3 * ms / c, 2), flop_per_launch=fl,
+                 algorithmic_bytes=by, k_slices=sk, achieved=round(ach, 2), frac=round(ach / peak, 4))
+        if wg and wg < 256:      # one 144-KiB workgroup per CU: the launch occupies wg of the 256 CUs by plan
+            e["frac_of_the_cus_it_occupies"] = round(ach / (peak * wg / 256), 4)
+        shapes.append(e)
     return dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                 launch_shapes=shapes,
                 traffic=traffic, traffic_source=traffic_src, algorithmic_bytes_per_launch=round(tbytes / n),

@@ -28,7 +28,7 @@ static thread_local const char* g_last_gather_name = "";
 // are outside the bracket).  The store is bounded: launches beyond TIMED_MAX while timing is on are not recorded.
 #include <mutex>
 #include <vector>
-struct TimedLaunch { hipEvent_t e0, e1; const char* name; double flop, bytes; int splitk; };
+struct TimedLaunch { hipEvent_t e0, e1; const char* name; double flop, bytes; int splitk, nwg; };
 static std::mutex g_timed_mu;
 static std::vector<TimedLaunch> g_timed;
 static std::atomic<bool> g_timing{false};
@@ -45,10 +45,10 @@ bool pfa_timing_begin(hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
     (void)hipEventRecord(*e0, st);
     return true;
 }
-void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk) {
+void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk, int nwg) {
     (void)hipEventRecord(e1, st);
     std::lock_guard<std::mutex> lk(g_timed_mu);
-    g_timed.push_back(TimedLaunch{e0, e1, name, flop, bytes, splitk});
+    g_timed.push_back(TimedLaunch{e0, e1, name, flop, bytes, splitk, nwg});
 }
 
 namespace {
@@ -1183,6 +1183,13 @@ extern "C" int pfa_gather_timing_get(int i, float* ms, const char** name, double
     return 0;
 }
 
+extern "C" int pfa_gather_timing_grid(int i, int* nwg) {
+    std::lock_guard<std::mutex> lk(g_timed_mu);
+    PFA_REQUIRE(i >= 0 && i < (int)g_timed.size() && nwg, "pfa_gather_timing_grid: bad arguments");
+    *nwg = g_timed[i].nwg;
+    return 0;
+}
+
 extern "C" int pfa_gather_timing_start(int i, int ref, float* start_ms) {
     std::lock_guard<std::mutex> lk(g_timed_mu);
     PFA_REQUIRE(i >= 0 && i < (int)g_timed.size() && ref >= 0 && ref < (int)g_timed.size() && start_ms,
@@ -1317,7 +1324,7 @@ extern "C" int pfa_gather_gemm(pfa_gather_args* a, pfa_stream s) {
         // unique operand + result bytes: both sources, the weight rows used, the output rows written
         const double bytes = es * ((double)a->nb * a->hs * a->ws * k.ctot + (double)k.n * 16.0 * k.ctot +
                                    (double)k.npix * (a->ld1 + a->ld2));
-        pfa_timing_end(st, te0, te1, g_last_gather_name, flop, bytes, k.splitk);
+        pfa_timing_end(st, te0, te1, g_last_gather_name, flop, bytes, k.splitk, patch ? ptiles * (a->n / pbn) * k.splitk : 0);
     }
     if (rc) return rc;
     if (defer) {

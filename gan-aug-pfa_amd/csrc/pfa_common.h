@@ -45,7 +45,7 @@ extern std::atomic<uint64_t> g_pfa_launches;
 extern std::atomic<int> g_knob[16];
 static inline int pfa_knob(int i) { return g_knob[i].load(std::memory_order_relaxed); }
 bool pfa_timing_begin(hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);      // false: timing is off (or the store is full)
-void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk);
+void pfa_timing_end(hipStream_t st, hipEvent_t e0, hipEvent_t e1, const char* name, double flop, double bytes, int splitk, int nwg = 0);   // nwg: the launch's workgroups where the caller knows them (else 0)
 
 extern void* g_pfa_dbgbuf;              // pfa_set_debug_buffer: device memory a kernel may write developer stamps to
 extern size_t g_pfa_dbgbuf_bytes;

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "pfa_gather_timing_get": (c_int, [c_int, POINTER(c_float), POINTER(c_char_p), POINTER(c_double), POINTER(c_double),
                                       POINTER(c_int)]),
     "pfa_gather_timing_start": (c_int, [c_int, c_int, POINTER(c_float)]),
+    "pfa_gather_timing_grid": (c_int, [c_int, POINTER(c_int)]),
     "pfa_gather_stat_tiles": (c_int, [POINTER(GatherArgs)]),
     "pfa_gather_slab_floats": (c_size_t, [POINTER(GatherArgs)]),
     "pfa_gather_gemm": (c_int, [POINTER(GatherArgs), c_void_p]),

@@ -105,6 +105,8 @@ int pfa_gather_timing_get(int i, float* ms, const char** name, double* flop, dou
 /* Start of timed launch i relative to the start of timed launch `ref`, in ms (launches of different streams compare: the
  * events are device timestamps) - an in-situ timeline of the MFMA kernels of a multi-stream step (tools/insitu_gantt.py). */
 int pfa_gather_timing_start(int i, int ref, float* start_ms);
+/* workgroups of timed launch i where the library recorded them (the stride-1 patch kernel), else 0 */
+int pfa_gather_timing_grid(int i, int* nwg);
 
 /* ------------------------------------------------------------------ implicit GEMM, MFMA
  * out[pix(m)][n] = act( bias[n] + sum_{tap,c} src[pix(m)+tap][c] * w[n][tap][c] )
