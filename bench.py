@@ -633,11 +633,15 @@ def main():
             # extra legs, AFTER the headline's timed region and roofline pass, each bounded to a fraction of a second of GPU
             # time: the parity mode on the same workload, and BASELINE config 5
             del trainer
-            torch.cuda.synchronize()
+            import gc
+            gc.collect()                             # the trainer's reference cycles: collected NOW, not in the middle of a leg
+            torch.cuda.synchronize()                 # (freeing its buffers synchronises the device: a leg measured 40 % low)
             try:
                 out["fp32"] = fp32_leg(args, pool_src)
             except Exception as e:                   # an extra leg never costs the headline line
                 out["fp32"] = {"value": None, "error": repr(e)[:300]}
+            gc.collect()                             # (the fp32 leg's trainer)
+            torch.cuda.synchronize()
             try:
                 out["infer"] = infer_leg(args)
             except Exception as e:
