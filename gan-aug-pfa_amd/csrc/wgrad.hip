@@ -42,6 +42,10 @@ struct WgradK {
     int kgroups;     // 1, or 2: K-group pairs (k_wgrad KG)
     int msplit;
     int fresh;       // dw holds zeros and this launch has one slice: store, do not add
+    // row-aligned geometry (k_wgrad<..., FAST>): a reduction step covers a piece of ONE row, whole rows or whole images, so a
+    // lane's place inside the step never changes and the step's position is one scalar
+    int rps;         // rows of the map a step covers (1 when it covers a piece of a row)
+    int xspan;       // columns of the map a step covers: min(KM, wq)
 };
 
 __device__ __forceinline__ int fastdiv(int n, int d, unsigned magic) {
@@ -64,7 +68,12 @@ template <typename F> __device__ __forceinline__ void pin(F& v) { asm volatile("
 // KG == 2 (bf16): two wave groups share one output tile and split every reduction step between them (KM = 128 pixels per
 // step, group g takes rows 64g..64g+63); their accumulators are added through LDS at the end.  Same waves per CU as two
 // independent 4-wave workgroups, half the partial tiles to write and reduce.
-template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1>
+// FAST (bf16, row-aligned geometry: wgrad_fast_ok): both operands staged with the buffer form of the LDS-DMA (pfa_common.h) - a
+// per-lane offset fixed for the whole loop, one scalar per operand and step, PFA_DMA_OOB for the lanes whose gathered pixel
+// falls outside the image at the edge the step touches.  The general staging below rebuilds a 64-bit pointer per piece
+// from per-lane pixel coordinates it advances with carries: 329 instructions per step for 32 MFMAs, half of them that
+// arithmetic (tools/issue_mix.py).
+template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1, bool FAST = false>
 __global__ __launch_bounds__(64 * WI * WJ * KG) __attribute__((amdgpu_waves_per_eu(2))) void k_wgrad(const WgradK p) {
     constexpr int NTO = 64 * WI * WJ;                // threads that own the output tile
     constexpr int NT = NTO * KG;                     // 256 threads (4 waves) or 512 (8 waves: the 256-row ring tile, KG = 2)
@@ -141,10 +150,58 @@ __global__ __launch_bounds__(64 * WI * WJ * KG) __attribute__((amdgpu_waves_per_
         g_qx[i] = rem - g_qy[i] * p.wq;
     }
 
+    // ---- FAST: per-lane offsets and edge bits of every piece, fixed for the loop
+    unsigned fd_off[FAST ? DIT : 1], fg_off[FAST ? GIT : 1], fg_bits[FAST ? GIT : 1];
+    const char* fd_base = nullptr;          // (wave-uniform) the direct tile's first column
+    const char* fg_base = nullptr;          // the gathered tensor, moved back by one row and one pixel: no offset is negative
+    int fd_ld = 0;
+    if constexpr (FAST) {
+        const bool first = i0 < p.d1p;      // (the tile lies inside one source: wgrad_fast_ok)
+        fd_base = first ? p.dir1 + (size_t)i0 * sizeof(T) : p.dir2 + (size_t)(i0 - p.d1p) * sizeof(T);
+        fd_ld = first ? p.d1p : p.d2p;
+        const bool d_ok = i0 + d_g * CH < p.dp;
+#pragma unroll
+        for (int i = 0; i < DIT; ++i) {
+            const int pi = i * (NT / RCD) + d_r0;
+            fd_off[i] = d_ok ? (unsigned)((pi * fd_ld + d_g * CH) * (int)sizeof(T)) : PFA_DMA_OOB;
+        }
+        fg_base = p.gat1 - (size_t)(p.wg + 1) * p.g1p * sizeof(T);
+        const int jc = j0 + g_g * CH;
+        const bool g_ok = jc < p.jtot;
+        const int tap = g_ok ? jc / p.gp : 0, c = jc - tap * p.gp;
+        const int ky = tap >> 2, kx = tap & 3;
+#pragma unroll
+        for (int i = 0; i < GIT; ++i) {
+            const int pi = i * (NT / RCG) + g_r0;                    // pixel inside the step
+            const int img = pi / hw, rem = pi - img * hw;            // (0, pi while a step stays inside one image)
+            const int ry = rem / p.wq, qx = rem - ry * p.wq;
+            const int pix = (img * p.hg + p.stride * ry + ky - 1) * p.wg + p.stride * qx + kx - 1 + p.wg + 1;
+            fg_off[i] = g_ok ? (unsigned)((pix * p.g1p + c) * (int)sizeof(T)) : PFA_DMA_OOB;
+            // the lane reads outside the image when the step touches: 1 the left edge, 2 the right, 4 the top, 8 the bottom
+            fg_bits[i] = (kx == 0 && qx == 0 ? 1u : 0u) | (kx == 3 && qx == p.xspan - 1 ? 2u : 0u) |
+                         (ky == 0 && ry == 0 ? 4u : 0u) | (ky == 3 && ry == p.rps - 1 ? 8u : 0u);
+        }
+    }
     auto stage = [&](int mstep, int buf) {
         if (p.dbg & 8) return;
         char* dbase = smem + buf * STAGE;
         char* gbase = dbase + D_BYTES;
+        if constexpr (FAST) {
+            // the step's place: image, row, column of its first pixel (scalars) -> one offset per operand, the edges it touches
+            const int ms = __builtin_amdgcn_readfirstlane(mstep);
+            const int ni = fastdiv(ms, hw, p.magic_hw), r = ms - ni * hw;
+            const int qy = fastdiv(r, p.wq, p.magic_wq), qx = r - qy * p.wq;
+            const unsigned edge = (qx == 0 ? 1u : 0u) | (qx + p.xspan == p.wq ? 2u : 0u) | (qy == 0 ? 4u : 0u) |
+                                  (qy + p.rps >= p.hq ? 8u : 0u);
+            const unsigned dso = (unsigned)ms * (unsigned)fd_ld * (unsigned)sizeof(T);
+            const unsigned gso = (unsigned)(((ni * p.hg + p.stride * qy) * p.wg + p.stride * qx) * p.g1p) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < DIT; ++i) buf_dma16(fd_base, dbase + (i * NT + wave * 64) * 16, fd_off[i], dso);
+#pragma unroll
+            for (int i = 0; i < GIT; ++i)
+                buf_dma16(fg_base, gbase + (i * NT + wave * 64) * 16, (fg_bits[i] & edge) ? PFA_DMA_OOB : fg_off[i], gso);
+            return;
+        }
         if (d_active) {
 #pragma unroll
             for (int i = 0; i < DIT; ++i) {
@@ -412,7 +469,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const WgradK p) {
     else atomicAdd(dst, tot);
 }
 
-template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1>
+template <typename T, int BI, int WI, int WJ, int EARLY, int KG = 1, bool FAST = false>
 int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     constexpr int KM = (sizeof(T) == 2 ? 64 : 32) * KG;
     constexpr size_t lds = (EARLY == 3 ? 3 : 2) * (KM * BI * sizeof(T) + KM * 128 * sizeof(T));
@@ -422,12 +479,12 @@ int launch_wgrad_v(WgradK k, int msplit, hipStream_t st) {
     dim3 grid(k.nwg);
     static std::atomic<bool> attr_done{false};   // (launches may come from several host threads)
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY, KG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_wgrad<T, BI, WI, WJ, EARLY, KG, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
         attr_done = true;
     }
     k.msplit = msplit;
-    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY, KG>), grid, dim3(64 * WI * WJ * KG), lds, st, k);
+    hipLaunchKernelGGL((k_wgrad<T, BI, WI, WJ, EARLY, KG, FAST>), grid, dim3(64 * WI * WJ * KG), lds, st, k);
     PFA_LAUNCHED("k_wgrad");
     if (k.slab) {
         hipLaunchKernelGGL((k_wgrad_reduce<BI, WI, WJ>),
@@ -496,6 +553,27 @@ static int wgrad_setup(const pfa_wgrad_args* a, WgradK& k, int& msplit, bool& sm
     return 0;
 }
 
+// Row-aligned geometry for k_wgrad<..., FAST>: bf16 on the 128-row tile, one gathered source, every 128-row tile inside one
+// direct source, a step (km pixels) that is a piece of one row, whole rows or whole images, no ragged last step, tensors
+// small enough for 32-bit offsets.  OPT-IN: pfa_set_knob(1, 32768).  Same bits as the general staging; per layer at B = 16
+// (tools/wgrad_bench.py) e2 / c2 36.5 -> 32.2 us, d5 34.0 -> 30.3, e5 24.4 -> 23.0, the one-step launches of the 2 x 2 maps +1 us
+// (the per-piece set-up divides); the step +0.5 % on one stream, -0.1 % eager / -0.6 ... -1.0 % through launch lists on three,
+// with every launch-size knob re-swept - so the default keeps the general staging.
+static bool wgrad_fast_ok(const pfa_wgrad_args* a, WgradK& k, int km) {
+    if (!(pfa_knob(1) & 32768)) return false;
+    if (a->dtype != PFA_BF16 || a->g2p != 0 || k.dp <= 16) return false;
+    if (a->d2p != 0 && a->d1p % 128 != 0) return false;
+    const int hw = a->hq * a->wq;
+    if (k.M % km != 0) return false;
+    if (!(a->wq % km == 0 || (km % a->wq == 0 && (hw % km == 0 || km % hw == 0)))) return false;
+    const long long dbytes = (long long)k.M * (a->d1p > a->d2p ? a->d1p : a->d2p) * 2;
+    const long long gbytes = ((long long)a->nb * a->hg * a->wg + a->wg + 2) * a->g1p * 2;
+    if (dbytes >= (1ll << 31) || gbytes >= (1ll << 31)) return false;
+    k.xspan = a->wq < km ? a->wq : km;
+    k.rps = a->wq >= km ? 1 : (km / a->wq < a->hq ? km / a->wq : a->hq);
+    return true;
+}
+
 // 256-row tile with the 3-stage ring: bf16 layers with at least 256 direct channels and a K loop long enough for a ring
 static bool wgrad_ring(const pfa_wgrad_args* a, const WgradK& k) {
     // (measured 3 % slower than the 128-row two-stage tile on the step's layers, tools/wgrad_bench.py: off unless knob 4 = 3)
@@ -539,8 +617,12 @@ extern "C" int pfa_wgrad(const pfa_wgrad_args* a, pfa_stream s) {
         msplit = pslices;
     } else if (a->dtype == PFA_BF16) {
         if (!small_i && wgrad_ring(a, k)) { rc = launch_wgrad_v<bf16_t, 256, 4, 2, 3>(k, msplit, st); name = "k_wgrad<bf16,256,ring>"; }
-        else if (k.kgroups == 2) { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st); name = "k_wgrad<bf16,128,kg2>"; }
+        else if (k.kgroups == 2) {
+            if (wgrad_fast_ok(a, k, 128)) { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2, true>(k, msplit, st); name = "k_wgrad<bf16,128,kg2,rows>"; }
+            else { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 1, 2>(k, msplit, st); name = "k_wgrad<bf16,128,kg2>"; }
+        }
         else if (small_i) { rc = launch_wgrad<bf16_t, 16, 1, 4>(k, msplit, st); name = "k_wgrad<bf16,16>"; }
+        else if (!k.early && wgrad_fast_ok(a, k, 64)) { rc = launch_wgrad_v<bf16_t, 128, 2, 2, 0, 1, true>(k, msplit, st); name = "k_wgrad<bf16,128,rows>"; }
         else { rc = launch_wgrad<bf16_t, 128, 2, 2>(k, msplit, st); name = "k_wgrad<bf16,128>"; }
     } else {
         rc = small_i ? launch_wgrad<float, 16, 1, 4>(k, msplit, st) : launch_wgrad<float, 128, 2, 2>(k, msplit, st);

@@ -56,7 +56,8 @@ uint64_t pfa_launch_count(void);
  * (bits 4, 8 and 128 apply to the two-stage loops and the rings that honour them - results are wrong when set); 1024 the slice-combining passes
  * (k_splitk_finish_vec, pfa_finish_bn_*) wait one round trip per slice, as before round 3; 4096 no four-image tiles for 8 x 8 maps
  * on the stride-2 / transposed patch kernels (they go back to the implicit GEMM's ring); 16384 the 256-row bf16 launches of the implicit GEMM on the
- * row kernel of conv_rows.hip (the patch kernels' K loop over gathered rows: built and tested, measured slower inside the step));
+ * row kernel of conv_rows.hip (the patch kernels' K loop over gathered rows: built and tested, measured slower inside the step)); 32768 the general weight-gradient kernel stages row-aligned
+ * geometries with per-lane offsets fixed for the loop (k_wgrad<...,rows>: same bits, faster per layer, no gain in the step);
  * id 2: gather K-loop (0 = default per tile, 1 = fragment reads before the next tile's DMA, 2 = DMA first, 3 = DMA spread
  * over the MFMAs); id 4: weight-gradient K-loop (0 = default: K-group pairs - two 4-wave groups per output tile -
  * from two reduction slices on, 1 = reads first, 2 = DMA first, 3 = 256-row 3-stage ring tile for >= 256 direct channels,

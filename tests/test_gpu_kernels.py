@@ -1151,6 +1151,72 @@ def test_wgrad_patch_kernel(case, ws):
     close(res[2], want, torch.float32, name + " two tap rows per workgroup")
 
 
+WG_ROWS_CASES = [  # name, kind, N, input channel parts, H, W of the layer INPUT, output channels, stride, slices
+    # (the patch kernel is kept off with knob 4 = 7 so that every case runs on wgrad.hip)
+    ("row_piece", "conv", 2, [32], 8, 256, 128, 2, 1),          # dy 4 x 128: a 64-pixel step is half a row (left / right edge steps differ)
+    ("row_piece_pairs", "conv", 2, [32], 8, 256, 128, 2, 4),    # the same on K-group pairs: a 128-pixel step is a whole row
+    ("rows", "conv", 4, [64], 32, 32, 128, 2, 2),               # dy 16 x 16: four rows per step (eight with pairs), top / bottom edge steps
+    ("image_per_step", "conv", 8, [64], 16, 16, 128, 2, 1),     # dy 8 x 8: a step is one image
+    ("images_per_step", "conv", 16, [32], 8, 8, 256, 2, 2),     # dy 4 x 4: four (eight) images per step; two 128-row tiles
+    ("tiny_maps", "conv", 64, [32], 4, 4, 128, 2, 1),           # dy 2 x 2: sixteen images per step
+    ("stride1", "conv", 4, [32], 17, 17, 128, 1, 2),            # stride 1: dy 16 x 16 from a 17 x 17 input
+    ("convT_cat", "convT", 4, [128, 128], 8, 8, 64, 2, 2),      # transposed: direct = two 128-channel inputs (a tile per source), gathered = dy 16 x 16
+    ("convT_deep", "convT", 16, [128], 4, 4, 32, 2, 1),         # transposed on 4 x 4 maps, four images per step
+]
+
+
+@pytest.mark.parametrize("case", WG_ROWS_CASES, ids=[c[0] for c in WG_ROWS_CASES])
+def test_wgrad_row_aligned_staging(case, ws):
+    """k_wgrad<..., rows>: where a reduction step is a piece of a row, whole rows or whole images, both operands are staged
+    with per-lane offsets fixed for the loop and one scalar per step (buffer-form LDS-DMA, hardware zero fill at the edges the
+    step touches; opt-in: pfa_set_knob(1, 32768)).  Same arithmetic in the same order as the general staging: the oracle, and
+    the SAME BITS as the default, through the slab combine and the fresh single-writer store."""
+    name, kind, n, cins, h, w, co, stride, msplit = case
+    dtype = torch.bfloat16
+    ci = sum(cins)
+    x = rnd(fill.uniform(name + ".wr.x", (n, ci, h, w)), dtype)
+    if kind == "conv":
+        ho, wo = (h + 2 - 4) // stride + 1, (w + 2 - 4) // stride + 1
+        dy = rnd(fill.uniform(name + ".wr.dy", (n, co, ho, wo)), dtype)
+        _, want, _ = ops.conv2d_bwd(x, fill.uniform(name + ".wr.w", (co, ci, 4, 4)), dy, stride, need_dx=False)
+        rows, cols = co, ci
+    else:
+        dy = rnd(fill.uniform(name + ".wr.dy", (n, co, 2 * h, 2 * w)), dtype)
+        _, want, _ = ops.convT2d_bwd(x, fill.uniform(name + ".wr.w", (ci, co, 4, 4)), dy, need_dx=False)
+        rows, cols = ci, co
+    srcs, o = [], 0
+    for c in cins:
+        srcs.append(to_nhwc(x[:, o:o + c], dtype))
+        o += c
+    dyt = to_nhwc(dy, dtype)
+    lib = _lib.lib()
+
+    def run(use_ws, fresh):
+        dw = torch.zeros((rows, 16, cols), dtype=torch.float32, device="cuda")
+        if kind == "conv":
+            K.wgrad([dyt], srcs, dw, stride, [co], cins, msplit=msplit, ws=use_ws, fresh=fresh)
+        else:
+            K.wgrad(srcs, [dyt], dw, 2, cins, [co], msplit=msplit, ws=use_ws, fresh=fresh)
+        torch.cuda.synchronize()
+        return dw
+
+    lib.pfa_set_knob(4, 7)
+    try:
+        got = {}
+        for knob1 in (0, 32768):
+            lib.pfa_set_knob(1, knob1)
+            kernel = _last_wgrad_kernel(lambda: run(K.FORCE_SLAB, False))
+            assert kernel.startswith("k_wgrad<bf16,128") and kernel.endswith(",rows>") == (knob1 == 32768), kernel
+            got[knob1] = [run(K.FORCE_SLAB, False), run(K.FORCE_SLAB if msplit > 1 else None, True)]
+    finally:
+        lib.pfa_set_knob(4, 0)
+        lib.pfa_set_knob(1, 0)
+    for dw in got[32768]:
+        close(dw.cpu().numpy().reshape(rows, 4, 4, cols).transpose(0, 3, 1, 2), want, torch.float32, name)
+    for a, b in zip(got[0], got[32768]):
+        assert torch.equal(a, b), name + ": the two stagings must give the same bits"
+
+
 @pytest.mark.parametrize("case", [("conv_co320", "conv", 2, [32], 32, 32, 320, 2), ("convT_ci256_cat", "convT", 2, [128, 128], 16, 16, 24, 2),
                                   ("conv_s1_co256", "conv", 2, [16], 23, 23, 256, 1)], ids=lambda c: c[0])
 def test_wgrad_ring_tile(case, ws):

@@ -49,7 +49,8 @@ def display(name):
             return "k_wgrad<bf16,16>"
         if a[0] == 256:
             return "k_wgrad<bf16,256,ring>"
-        return "k_wgrad<bf16,128,kg2>" if len(a) >= 5 and a[4] == 2 else "k_wgrad<bf16,128>"
+        rows = ",rows" if ("Lb1" in tail or "true" in tail) else ""          # the row-aligned staging (FAST)
+        return f"k_wgrad<bf16,128,kg2{rows}>" if len(a) >= 5 and a[4] == 2 else f"k_wgrad<bf16,128{rows}>"
     if "k_gather_gemm" in name:
         tail = name.split("k_gather_gemm")[1][:70]
         a = [int(x) for x in re.findall(r"(?:Li|, ?)(\d+)", tail)][:5]

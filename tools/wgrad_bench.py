@@ -1,6 +1,7 @@
 """Per-layer timing of pfa_wgrad on the BASELINE config-2 shapes (B=16, 256x256, bf16)."""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/gan-aug-pfa_amd')
+import os
 import torch
 from pfa_gan import kernels as K
 WS = K.Workspace(torch.device('cuda'))
@@ -23,14 +24,13 @@ L = [("e1", (128,128,[64]), (256,256,[8]), 2, [64], [3]),
      ("d3", (32,32,[256,256]), (64,64,[128]), 2, [256,256], [128]),
      ("d2", (64,64,[128,128]), (128,128,[64]), 2, [128,128], [64]),
      ("d1", (128,128,[64,64]), (256,256,[8]), 2, [64,64], [3])]
-import os
 from pfa_gan import _lib as _L
 _L.lib().pfa_set_knob(4, int(os.environ.get("WG_LOOP", "0")))     # knob 4: 1 reads first, 2 DMA first, 3 ring tile
 tot=0
 for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in L:
     d=[T(B,dh,dw,c) for c in dcs]; g=[T(B,gh,gw,c) for c in gcs]
     dwt=torch.zeros(sum(dreal)*16*sum(greal), device='cuda')
-    f=lambda: K.wgrad(d,g,dwt,stride,dreal,greal,ws=WS)
+    f=lambda: K.wgrad(d,g,dwt,stride,dreal,greal,ws=WS,fresh=os.environ.get('WG_FRESH','1')=='1')      # (fresh: as the engines call it - a zeroed arena)
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
@@ -40,7 +40,8 @@ for name,(dh,dw,dcs),(gh,gw,gcs),stride,dreal,greal in L:
     us=e0.elapsed_time(e1)*1e3/20
     flop=2.0*B*dh*dw*sum(dreal)*16*sum(greal)
     tot+=us
-    print(f"{name:6s} {us:8.1f} us {flop/us/1e6:7.0f} TF/s")
+    obytes=4.0*sum(dreal)*16*sum(greal)
+    print(f"{name:6s} {us:8.1f} us {flop/us/1e6:7.0f} TF/s   dw {obytes/1e6:6.1f} MB = {obytes/us/1e6:5.2f} TB/s")
 print("total", tot)
 # ablation on two layers
 from pfa_gan import _lib
