@@ -31,6 +31,7 @@ struct ScatterK {
     int n, ld;               // real output channels, padded output row length (elements)
     int act;
     float slope;
+    int relu1;               // source 1's fragments pass through ReLU (pfa_scatter_args.relu_src1)
     int ty_tiles, tx_tiles;
     int kchunks, k1chunks;   // 128-byte K chunks in total / coming from src1
     const char* l1_fake;     // fused L1 + Tanh' epilogue (pfa_hip.h), or NULL
@@ -45,6 +46,12 @@ template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ f32x4 run(const frag& a, const frag& b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    // max(x, 0) on eight bf16: as 16-bit integers a negative value (sign bit) is a negative integer - one v_pk_max_i16 per pair
+    static __device__ __forceinline__ frag relu(const frag& a) {
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_bit_cast(frag, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), z));
+    }
 };
 template <> struct Mma<float> {
     typedef f32x4 frag;
@@ -52,6 +59,12 @@ template <> struct Mma<float> {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
         return c;
+    }
+    static __device__ __forceinline__ frag relu(const frag& a) {
+        frag r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = a[j] <= 0.f ? 0.f : a[j];
+        return r;
     }
 };
 
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(256) void k_tconv_scatter(const ScatterK p) {
             for (int b = 0; b < FM; ++b) {
                 const int row = wave * 64 + b * 16 + lrow;
                 af[b] = *(const typename Mma<T>::frag*)(smem + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+                if (p.relu1 && !second) af[b] = Mma<T>::relu(af[b]);
             }
 #pragma unroll
             for (int a = 0; a < FN; ++a)
@@ -281,7 +295,7 @@ extern "C" int pfa_tconv_scatter(const pfa_scatter_args* a, pfa_stream s) {
     k.bias = a->bias; k.out = (char*)a->out;
     k.nb = a->nb; k.hs = a->hs; k.ws = a->ws;
     k.c1 = a->c1; k.c2 = a->c2; k.ctot = a->c1 + a->c2;
-    k.n = a->n; k.ld = a->ld; k.act = a->act; k.slope = a->slope;
+    k.n = a->n; k.ld = a->ld; k.act = a->act; k.slope = a->slope; k.relu1 = a->relu_src1 != 0;
     PFA_REQUIRE((a->l1_fake == nullptr) == (a->l1_real == nullptr), "pfa_tconv_scatter: l1_fake and l1_real come together");
     PFA_REQUIRE(!a->l1_fake || (a->act == PFA_ACT_NONE && !a->bias && a->l1_creal > 0 && a->l1_creal <= a->n),
                 "pfa_tconv_scatter: the fused L1 epilogue takes a plain input-gradient launch (no bias / activation), 0 < l1_creal <= n");

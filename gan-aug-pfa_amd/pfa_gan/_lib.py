@@ -46,7 +46,7 @@ class ScatterArgs(Structure):
     _fields_ = [
         ("struct_size", c_int32), ("dtype", c_int32), ("nb", c_int32), ("hs", c_int32), ("ws", c_int32),
         ("c1", c_int32), ("c2", c_int32), ("n", c_int32), ("ld", c_int32), ("act", c_int32), ("slope", c_float),
-        ("reserved", c_int32),
+        ("relu_src1", c_int32),
         ("src1", c_void_p), ("src2", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("out", c_void_p),
         ("l1_fake", c_void_p), ("l1_real", c_void_p), ("l1_lambda", c_float), ("l1_creal", c_int32),
     ]

@@ -22,7 +22,7 @@ class _GeneratorFn(torch.autograd.Function):
         eng.refresh_shadows(force=module.training)
         ctx = eng.new_ctx() if needs_grad else eng.scratch_ctx()
         xh = K.pack_nhwc(x, eng.dtype)
-        fake = eng.forward(xh, ctx, train=module.training, bn_repeats=1)
+        fake = eng.forward(xh, ctx, train=module.training, bn_repeats=1, differentiable=needs_grad or module.training)
         fctx.eng, fctx.ctx = eng, ctx
         return K.unpack_nchw(fake, eng.out_nc)
 

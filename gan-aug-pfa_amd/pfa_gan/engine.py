@@ -511,6 +511,9 @@ class _Engine:
         return dr
 
 
+ONE_COPY_E1 = os.environ.get("PFA_ONE_COPY_E1", "1") != "0"      # A/B switch: eval forward without the ReLU copy of e1's activation
+
+
 # ------------------------------------------------------------------------------------ generator
 class GeneratorEngine(_Engine):
     """UNetGenerator.forward / backward (models.py:163-208) on the HIP kernels."""
@@ -538,8 +541,11 @@ class GeneratorEngine(_Engine):
         self.layers = self.down + self.up
         self.out_nc = self.up[0].cout
 
-    def forward(self, x, ctx, train=True, bn_repeats=1):
-        """x: NHWC [B,H,W,cp_in].  Returns tanh output NHWC [B,H,W,cp_out] (pad channels zero)."""
+    def forward(self, x, ctx, train=True, bn_repeats=1, differentiable=None):
+        """x: NHWC [B,H,W,cp_in].  Returns tanh output NHWC [B,H,W,cp_out] (pad channels zero).
+        differentiable (default: train): a backward over this context may follow - the forward keeps every tensor it reads."""
+        if differentiable is None:
+            differentiable = train
         D, dt = self.D, self.dtype
         B, H, W, _ = x.shape
         if H % (1 << D) or W % (1 << D):
@@ -556,6 +562,17 @@ class GeneratorEngine(_Engine):
                 K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aR], (B, h, w), self.ws, act=K.ACT_RELU)
                 ctx.v["aR"][k] = aR
                 break
+            if k == 0 and not train and not differentiable and ONE_COPY_E1 and D > 1 and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w), L.cout_p) \
+                    and K.tconv_scatter_ok_ch(dt, L.cout_p, self.up[1].cout_p, self.up[0].cout, self.up[0].cout_p):
+                # eval: ONE copy of the outermost encoder activation (the largest tensor of the forward: 134 MB at batch 64).
+                # The last layer takes ReLU of it, and relu(lrelu(y)) == relu(y): its kernel applies max(x, 0) to the staged
+                # operand (pfa_scatter_args.relu_src1) instead of this launch writing a second, ReLU copy
+                aL = ctx.buf(f"e{k}.aL", shape, dt)
+                K.gather_gemm(K.CONV_S2, [a], L.w_fwd, L.cout, [aL], (B, h, w), self.ws, act=K.ACT_LRELU,
+                              affine=self._eval_affine(L, ctx, f"e{k}") + (K.ACT_NONE,), c_real=sum(L.in_real))
+                ctx.v["aL"][k], ctx.v["aR"][k] = aL, None
+                a = aL
+                continue
             aL, aR = ctx.buf(f"e{k}.aL", shape, dt), ctx.buf(f"e{k}.aR", shape, dt)
             if (not train or L.bn is None) and self._affine_ok(K.CONV_S2, [a], L.cout, (B, h, w), L.cout_p):
                 # eval: the normalisation is a per-channel affine map known up front - apply it in the GEMM epilogue
@@ -591,6 +608,10 @@ class GeneratorEngine(_Engine):
             ctx.v["uR"][k] = uR
         L = self.up[0]
         fake = ctx.buf("fake", (B, H, W, L.cout_p), dt)
+        if ctx.v["aR"][0] is None:                         # eval, one copy of e1's activation: ReLU on the operand's way in
+            K.tconv_scatter([ctx.v["aL"][0], ctx.v["uR"][1]], L.w_fwd, L.cout, fake, bias=L.b, act=K.ACT_TANH, relu_src1=True)
+            ctx.v["fake"] = fake
+            return fake
         srcs = [ctx.v["aR"][0], ctx.v["uR"][1]]
         if K.tconv_scatter_ok(srcs, L.cout, fake):        # few output channels: pointwise GEMM + col2im
             K.tconv_scatter(srcs, L.w_fwd, L.cout, fake, bias=L.b, act=K.ACT_TANH)

@@ -298,7 +298,12 @@ def tconv_scatter_ok(srcs, n, out):
     return bool(lib().pfa_tconv_scatter_supported(dt_code(srcs[0].dtype), srcs[0].shape[3], c2, n, out.shape[3]))
 
 
-def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE, l1=None):
+def tconv_scatter_ok_ch(dtype, c1, c2, n, ld):
+    """tconv_scatter_ok from channel counts alone (the engine decides before the second source exists)."""
+    return SCATTER and bool(lib().pfa_tconv_scatter_supported(dt_code(dtype), c1, c2, n, ld))
+
+
+def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE, l1=None, relu_src1=False):
     """out = act(bias + ConvTranspose2d_{k4,s2,p1}([srcs]))) for n <= 8 output channels: pointwise MFMA GEMM per input
     patch + col2im in LDS (csrc/tconv_scatter.hip).  Same operands and result as gather_gemm(TCONV_S2, ...).
     l1 = (fake, real, c_real, lambda): the generator phase's fused epilogue - `out` receives dL/dpre of the generator's
@@ -312,6 +317,7 @@ def tconv_scatter(srcs, w, n, out, bias=None, act=ACT_NONE, l1=None):
     a.c2 = srcs[1].shape[3] if len(srcs) > 1 else 0
     a.n, a.ld = n, out.shape[3]
     a.act, a.slope = act, SLOPE
+    a.relu_src1 = 1 if relu_src1 else 0          # source 1 is the LeakyReLU copy of a tensor whose ReLU the layer takes
     a.src1, a.src2 = ptr(srcs[0]), ptr(srcs[1]) if len(srcs) > 1 else None
     a.w, a.bias, a.out = ptr(w), ptr(bias), ptr(out)
     if l1 is not None:

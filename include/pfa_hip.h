@@ -254,7 +254,8 @@ typedef struct pfa_scatter_args {
     int32_t n, ld;
     int32_t act;
     float slope;
-    int32_t reserved;
+    int32_t relu_src1;           /* != 0: source 1 enters through ReLU (max(x, 0) on the staged operand): the eval forward keeps ONE copy of the
+                                  * outermost encoder activation, the LeakyReLU one, and relu(lrelu(y)) == relu(y) (models.py:180,185) */
     const void* src1;
     const void* src2;
     const void* w;

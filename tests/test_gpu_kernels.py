@@ -853,6 +853,35 @@ def test_tconv_scatter(case, dtype, ws):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
+@pytest.mark.parametrize("cins", [[64, 64], [64], [128, 64]], ids=["d1_like", "one_source", "uneven"])
+def test_tconv_scatter_relu_on_the_first_source(cins, dtype):
+    """pfa_scatter_args.relu_src1: the first source enters through max(x, 0) (the eval forward hands the last layer the
+    LeakyReLU copy of e1's activation) - the same bits as the launch on a materialised ReLU copy; the second source untouched."""
+    n, h, w, co = 2, 9, 35, 3
+    ci = sum(cins)
+    y = rnd(fill.uniform("relu1.y", (n, ci, h, w), -2, 2), dtype)
+    y[0, 0, 0, :4] = [-0.0, 0.0, -1e-30, 1e-30]
+    wt = rnd(fill.uniform("relu1.w", (ci, co, 4, 4), -0.25, 0.25), dtype)
+    _, tr = shadows(wt, dtype, want=("tr",))
+    lre = np.where(y > 0, y, 0.2 * y).astype(np.float32)                       # what the encoder stores: LeakyReLU(y)
+    srcs, srcs_relu, o = [], [], 0
+    for i, c in enumerate(cins):
+        part = rnd(lre[:, o:o + c], dtype)
+        srcs.append(to_nhwc(part, dtype))
+        srcs_relu.append(to_nhwc(np.maximum(part, 0) if i == 0 else part, dtype))
+        o += c
+    cp = K.pad_ch(co, dtype)
+    a = torch.full((n, 2 * h, 2 * w, cp), 7.0, dtype=dtype, device="cuda")
+    b = torch.full_like(a, 5.0)
+    K.tconv_scatter(srcs, tr, co, a, act=K.ACT_TANH, relu_src1=True)
+    K.tconv_scatter(srcs_relu, tr, co, b, act=K.ACT_TANH)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    x = np.concatenate([np.maximum(lre[:, :cins[0]], 0)] + ([lre[:, cins[0]:]] if len(cins) > 1 else []), axis=1)
+    close(from_nhwc(a, co), np.tanh(ops.convT2d_fwd(rnd(x, dtype), wt, None)), dtype, "relu on load")
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=DT_IDS)
 @pytest.mark.parametrize("case", [("c1_dgrad", 2, 64, 13, 31, 3), ("ragged", 1, 64, 7, 33, 3), ("six", 2, 128, 6, 30, 6)],
                          ids=lambda c: c[0])
 def test_tconv_scatter_fused_l1_tanh_epilogue(case, dtype, ws):
