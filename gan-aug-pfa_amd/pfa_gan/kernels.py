@@ -645,7 +645,9 @@ def colsum(x, out, ws, c_out=None):
 
 
 # ------------------------------------------------------------------------------- Adam, shadows, layout
-def adam(p, g, m, v, lr, b1, b2, eps, step, step_dev=None, grad_scale=1.0, g2=None):
+def adam(p, g, m, v, lr, b1, b2, eps, step, step_dev=None, grad_scale=1.0, g2=None, grid=0):
+    """grid: workgroups of the launch (0 = the library's default, 2048).  Every call states it: the setting is process-wide."""
+    lib().pfa_set_knob(11, int(grid))
     check(lib().pfa_adam(ptr(p), ptr(g), ptr(g2), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, int(step),
                          ptr(step_dev), float(grad_scale), stream()), "pfa_adam")
 

@@ -34,6 +34,7 @@ EARLY_G_ZERO = _os.environ.get("PFA_EARLY_G_ZERO", "1") != "0"       # zero the 
 DEFER_DECODER_UPDATE = _os.environ.get("PFA_DEFER_DECODER_UPDATE", "0") != "0"   # measured -2.0 %: off (see GanTrainer._d_update_g_phase)
 # dL/dpre from the launch that computes dL/dfake: measured -0.2 % at 256x256 and -0.9 % at 512x512 (the loss-only L1 pass on
 # the side stream collides with the HBM-bound first launches of the generator backward): off
+ADAM_GRID_BF16 = int(_os.environ.get("PFA_ADAM_GRID", "256"))          # workgroups of the Adam launches in bf16 mode (A/B switch)
 L1_FUSED = _os.environ.get("PFA_L1_FUSED", "0") != "0"
 # Adam + weight copies in one pass: 25 % less kernel time alone (0.27 against 0.36 ms per step on one stream), but in the
 # three-stream step +-0 at 256x256 and -0.8 % at 512x512 (three same-box pairs each): built, tested bit for bit, off
@@ -54,6 +55,10 @@ class FusedAdam(torch.optim.Optimizer):
             raise PfaError("FusedAdam supports a single parameter group")
         self._flat = None
         self.m = self.v = None
+        # workgroups of the Adam launches (0 = the library's 2048).  GanTrainer sets 256 in bf16 mode: one workgroup per CU
+        # moves the same bytes per second when the launch runs alone and takes less from the kernels it runs beside - same-box
+        # A/B +1.1 ... +1.4 % at B = 16 and 64, +0.7 % at 512 x 512, +0.5 % at batch 1; in fp32 mode -1.0 % (stays 2048)
+        self.grid = 0
         self.steps = 0          # host step count: THE step count (eager launches pass it by value)
         self.step_dev = None    # device copy read by captured launches; _dev_steps = the value it holds
         self._dev_steps = 0
@@ -108,10 +113,10 @@ class FusedAdam(torch.optim.Optimizer):
             K.adam_tick(self.step_dev)
             self._dev_steps += 1
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], 0,
-                   step_dev=self.step_dev, grad_scale=grad_scale, g2=g2)
+                   step_dev=self.step_dev, grad_scale=grad_scale, g2=g2, grid=self.grid)
         else:
             K.adam(flat.data, flat.grad, self.m, self.v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.steps,
-                   grad_scale=grad_scale, g2=g2)
+                   grad_scale=grad_scale, g2=g2, grid=self.grid)
 
     @torch.no_grad()
     def step_begin(self, graph_safe=False):
@@ -137,10 +142,10 @@ class FusedAdam(torch.optim.Optimizer):
         g2 = self._grad2[lo:hi] if use_grad2 else None
         if getattr(self, "_range_dev", False):
             K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
-                   g["eps"], 0, step_dev=self.step_dev, grad_scale=grad_scale, g2=g2)
+                   g["eps"], 0, step_dev=self.step_dev, grad_scale=grad_scale, g2=g2, grid=self.grid)
             return
         K.adam(flat.data[lo:hi], flat.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], g["betas"][0], g["betas"][1],
-               g["eps"], self.steps, grad_scale=grad_scale, g2=g2)
+               g["eps"], self.steps, grad_scale=grad_scale, g2=g2, grid=self.grid)
 
     def state_dict(self):
         self.flat()
@@ -192,6 +197,7 @@ class GanTrainer:
             if not isinstance(o, FusedAdam):
                 raise PfaError("GanTrainer drives pfa_gan.FusedAdam optimizers (same hyper-parameters as optim.Adam)")
         self.opt_g.flat(), self.opt_d.flat()
+        self.opt_g.grid = self.opt_d.grid = ADAM_GRID_BF16 if self.dtype == torch.bfloat16 else 0      # (see FusedAdam.grid)
         self.lambda_l1 = float(lambda_l1)
         self.pg = process_group
         if grad_payload not in (None, "bf16"):
