@@ -2,9 +2,12 @@
 import csv, glob, sys
 d = sys.argv[1]
 rows = sorted(csv.DictReader(open(glob.glob(f'{d}/*/*_kernel_trace.csv')[0])), key=lambda r: int(r['Start_Timestamp']))
-# last step = between the last two generator-sized adam launches
-idx = [i for i, r in enumerate(rows) if 'k_adam(' in r['Kernel_Name'] and int(r['Grid_Size_X']) > 256 * 1000]
-start, end = idx[-3] + 1, idx[-1] + 1          # two adam launches (D, G) per step: last full step
+# last step = from behind the last Adam launch of the step before to the last Adam launch of the run (the bench runs
+# STEPS steps in all: warm-up + timed; every step has the same number of Adam launches)
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+idx = [i for i, r in enumerate(rows) if 'k_adam(' in r['Kernel_Name']]
+per = max(1, len(idx) // STEPS)
+start, end = idx[-per - 1] + 1, idx[-1] + 1
 seg = rows[start:end]
 t0, t1 = int(seg[0]['Start_Timestamp']), int(seg[-1]['End_Timestamp'])
 print(f"step wall {(t1 - t0) / 1e3:.1f} us, {len(seg)} launches")
