@@ -363,7 +363,7 @@ def comm_diagnostics(trainer, pool, args, world, barrier, ms_with):
         torch.cuda.synchronize()
         ms = tmax(1e3 * (time.perf_counter() - t0) / reps)
         probe.append(dict(range=name, mbytes=round(n * esize / 1e6, 2), ms=round(ms, 3),
-                          busbw_gbs=round(2 * (world - 1) / world * n * esize / (ms * 1e-3) / 1e9, 1)))
+                          busbw_gbs=round(2 * (world - 1) / world * n * esize / (ms * 1e-3) / 1e9, 3)))   # (3 decimals: a 0.5 MB range over a slow transport - the gloo rehearsal - must not round to 0)
         del buf
     trainer.skip_collectives = True
     try:
