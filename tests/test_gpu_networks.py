@@ -607,7 +607,10 @@ def _torchrun(script_args, env_extra, timeout=600):
     env = dict(os.environ)
     env.update(env_extra)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    port = 29700 + os.getpid() % 200
+    import socket
+    with socket.socket() as sk:             # a free port per call (a fixed one can still be held by the previous run's store)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout)
